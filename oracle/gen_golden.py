@@ -1,0 +1,360 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own model files (build container only).
+
+TEST INFRASTRUCTURE.  Run as ``python oracle/gen_golden.py`` from the repo root in a container that
+has /root/reference.  The reference package cannot be imported normally here (gym, ml_logger,
+diffusers, ... are absent: ordinary ModuleNotFoundError), so its model files are loaded one by one
+with importlib under small stub modules.  The only arithmetic that does NOT
+come from the reference is the third-party diffusers==0.24.0 scheduler, stubbed with
+oracle.madiff_oracle.DDPMSchedule (parity unpinned for that part).
+
+Nothing from the reference is written to the repo except numeric inputs/outputs (.npz, no pickles).
+Weights are the closed-form fill of oracle.madiff_oracle.closed_form_param, so fixtures only hold
+inputs, recorded random draws, outputs and gradient digests.
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib.util
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import madiff_oracle as O  # noqa: E402
+
+REF = "/root/reference/diffuser"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+# ---------------------------------------------------------------- stubs + reference loading
+class _SchedOut:
+    def __init__(self, prev_sample):
+        self.prev_sample = prev_sample
+
+
+class _Cfg:
+    pass
+
+
+class StubDDPMScheduler(O.DDPMSchedule):
+    def __init__(self, num_train_timesteps, clip_sample=True, prediction_type="epsilon",
+                 beta_schedule="squaredcos_cap_v2"):
+        assert clip_sample and prediction_type == "epsilon" and beta_schedule == "squaredcos_cap_v2"
+        super().__init__(num_train_timesteps)
+        self.config = _Cfg()
+        self.config.num_train_timesteps = num_train_timesteps
+
+    def step(self, model_output, t, x):
+        z = torch.randn(x.shape) if int(t) > 0 else None   # recorded by the randn wrapper
+        return _SchedOut(O.DDPMSchedule.step(self, model_output, int(t), x, z))
+
+
+class StubDDIMScheduler(StubDDPMScheduler):
+    def set_timesteps(self, n):
+        self._ddim = O.DDIMSchedule(self.K, n)
+        self.timesteps = self._ddim.timesteps
+
+    def step(self, model_output, t, x):
+        return _SchedOut(self._ddim.step(model_output, int(t), x))
+
+
+def load_reference():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Encoder:
+        def __call__(self, d):
+            raise NotImplementedError
+
+    class IdentityEncoder(Encoder):
+        def __call__(self, d):
+            return d
+
+    class Silent:
+        def __init__(self, *a, **k):
+            pass
+
+        def update(self, *a, **k):
+            pass
+
+        def close(self):
+            pass
+
+    d = mod("diffuser")
+    d.__path__ = [REF]
+    u = mod("diffuser.utils", Encoder=Encoder, IdentityEncoder=IdentityEncoder, Progress=Silent, Silent=Silent,
+            to_np=lambda x: x.detach().cpu().numpy(), to_torch=lambda x, **k: torch.as_tensor(x))
+    d.utils = u
+    m = mod("diffuser.models")
+    m.__path__ = [REF + "/models"]
+    mod("diffusers")
+    mod("diffusers.schedulers")
+    mod("diffusers.schedulers.scheduling_ddpm", DDPMScheduler=StubDDPMScheduler)
+    mod("diffusers.schedulers.scheduling_ddim", DDIMScheduler=StubDDIMScheduler)
+    out = {}
+    for name in ("helpers", "temporal", "ma_temporal", "diffusion"):
+        spec = importlib.util.spec_from_file_location(f"diffuser.models.{name}", f"{REF}/models/{name}.py")
+        mm = importlib.util.module_from_spec(spec)
+        sys.modules[f"diffuser.models.{name}"] = mm
+        spec.loader.exec_module(mm)
+        out[name] = mm
+    return out
+
+
+class Recorder:
+    """Record every random draw the reference makes (order preserved)."""
+
+    def __init__(self, closed_form_randn: str = ""):
+        self.draws = []
+        self._orig = {}
+        self._cf = closed_form_randn   # if set: torch.randn draw i is REPLACED by closed_form_normal(f"{tag}.{i}")
+        self._n = 0
+
+    def __enter__(self):
+        rec = self
+
+        def wrap(fn, tag):
+            def inner(*a, **k):
+                r = fn(*a, **k)
+                rec.draws.append((tag, r.detach().clone()))
+                return r
+            return inner
+
+        self._orig = {"randn": torch.randn, "randn_like": torch.randn_like, "randint": torch.randint,
+                      "bern": torch.distributions.Bernoulli.sample}
+        if self._cf:
+            def cf_randn(*shape, **k):
+                shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+                r = torch.from_numpy(O.closed_form_normal(f"{rec._cf}.{rec._n}", shape))
+                rec._n += 1
+                rec.draws.append(("randn", r.clone()))
+                return r
+            torch.randn = cf_randn
+        else:
+            torch.randn = wrap(torch.randn, "randn")
+        torch.randn_like = wrap(torch.randn_like, "randn_like")
+        torch.randint = wrap(torch.randint, "randint")
+        torch.distributions.Bernoulli.sample = wrap(torch.distributions.Bernoulli.sample, "bern")
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn = self._orig["randn"]
+        torch.randn_like = self._orig["randn_like"]
+        torch.randint = self._orig["randint"]
+        torch.distributions.Bernoulli.sample = self._orig["bern"]
+
+    def of(self, tag):
+        return [d for (t, d) in self.draws if t == tag]
+
+
+def fill_closed_form(module, prefix=""):
+    sd = module.state_dict()
+    new = {k: O.closed_form_param(prefix + k, tuple(v.shape)) if v.dtype.is_floating_point and "loss_fn" not in k
+           else v for k, v in sd.items()}
+    module.load_state_dict(new)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def grad_digest(named_grads):
+    """Per-parameter (sum, abs-sum, l2) so a 1M-parameter gradient fits in a few KB."""
+    names, rows = [], []
+    for k, g in named_grads:
+        names.append(k)
+        g = g.double()
+        rows.append([g.sum().item(), g.abs().sum().item(), g.pow(2).sum().sqrt().item()])
+    return np.array(names), np.array(rows, dtype=np.float64)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        conv[k] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def u(name, shape, lo=-1.0, hi=1.0):
+    return torch.from_numpy(O.closed_form_uniform("input:" + name, shape, lo, hi).astype(np.float32))
+
+
+# ---------------------------------------------------------------- G1: leaf modules
+def gen_modules(R):
+    H, T = R["helpers"], R["temporal"]
+    out = {}
+
+    def run(tag, module, inputs, prefix):
+        fill_closed_form(module, prefix)
+        ins = [i.clone().requires_grad_(i.dtype.is_floating_point) for i in inputs]
+        y = module(*ins)
+        gy = u(tag + ".gy", tuple(y.shape))
+        y.backward(gy)
+        out[tag + ".y"] = y
+        out[tag + ".gy"] = gy
+        for j, i in enumerate(ins):
+            out[f"{tag}.in{j}"] = i.detach()
+            if i.grad is not None:
+                out[f"{tag}.gin{j}"] = i.grad
+        for k, p in module.named_parameters():
+            out[f"{tag}.gp.{k}"] = p.grad
+
+    run("cblock", H.Conv1dBlock(12, 32, 5), [u("cblock.x", (3, 12, 8))], "cblock.")
+    run("rtb_proj", T.ResidualTemporalBlock(12, 32, embed_dim=20), [u("rtb_proj.x", (3, 12, 8)), u("rtb_proj.t", (3, 20))], "rtb_proj.")
+    run("rtb_same", T.ResidualTemporalBlock(32, 32, embed_dim=20), [u("rtb_same.x", (3, 32, 6)), u("rtb_same.t", (3, 20))], "rtb_same.")
+    run("down", H.Downsample1d(16), [u("down.x", (3, 16, 14))], "down.")
+    run("down_odd", H.Downsample1d(16), [u("down_odd.x", (3, 16, 7))], "down_odd.")
+    run("up", H.Upsample1d(16), [u("up.x", (3, 16, 7))], "up.")
+    att = T.TemporalSelfAttention(64, 4, 16, embed_dim=20, residual=True)
+    run("attn", att, [u("attn.x", (2, 5, 64, 6)), u("attn.t", (2, 5, 20))], "attn.")
+    emb = H.SinusoidalPosEmb(32)
+    out["posemb.t"] = torch.tensor([[0, 1, 7], [100, 199, 42]])
+    out["posemb.y"] = emb(out["posemb.t"])
+    save("g1_modules", **out)
+
+
+# ---------------------------------------------------------------- G2/G3: whole denoiser
+SHAPES = {  # name: (A, T, F, hh)
+    "spread": (3, 24, 18, 0), "tag": (3, 24, 16, 0), "ant": (4, 28, 54, 18), "smac": (8, 24, 88, 20),
+}
+
+
+def gen_denoiser(R, width, shapes, tag, with_grads):
+    M = R["ma_temporal"]
+    out = {}
+    for name in shapes:
+        A, T, Fd, hh = SHAPES[name]
+        B = 2
+        net = quiet(M.SharedConvAttentionDeconv, horizon=T, transition_dim=Fd, dim=width, history_horizon=hh,
+                    dim_mults=(1, 4, 8), n_agents=A, returns_condition=True, condition_dropout=0.25)
+        fill_closed_form(net, "model.")
+        x = u(f"{tag}.{name}.x", (B, T, A, Fd))
+        t = torch.tensor([3, 151])
+        ret = u(f"{tag}.{name}.ret", (B, 1, A), 0.0, 1.0)
+        with torch.no_grad():
+            y_c = net(x, t, returns=ret, use_dropout=False)
+            y_u = net(x, t, returns=ret, use_dropout=False, force_dropout=True)
+        with Recorder() as rec:
+            xg = x.clone().requires_grad_(True)
+            y_d = net(xg, t, returns=ret, use_dropout=True)
+        mask = rec.of("bern")[0]
+        out.update({f"{name}.x": x, f"{name}.t": t, f"{name}.returns": ret, f"{name}.y_cond": y_c,
+                    f"{name}.y_uncond": y_u, f"{name}.dropout_mask": mask, f"{name}.y_drop": y_d})
+        if with_grads:
+            gy = u(f"{tag}.{name}.gy", tuple(y_d.shape))
+            y_d.backward(gy)
+            names, rows = grad_digest([(k, p.grad) for k, p in net.named_parameters() if p.grad is not None])
+            out[f"{name}.gy"] = gy
+            out[f"{name}.gx"] = xg.grad
+            out[f"{name}.gp_names"] = names
+            out[f"{name}.gp_digest"] = rows
+            out[f"{name}.nograd_names"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+            for k in ("net.final_conv.1.bias", "self_attn.0.gamma", "self_attn.2.gamma",
+                      "net.mid_block1.blocks.0.block.2.weight", "net.downs.0.0.time_mlp.1.bias",
+                      "net.returns_mlp.0.weight"):
+                out[f"{name}.gp.{k}"] = dict(net.named_parameters())[k].grad
+    save(tag, **out)
+
+
+# ---------------------------------------------------------------- G4/G6: diffusion wrapper
+def build_diffusion(R, name, width, K, discrete=False, share_inv=True):
+    M, D = R["ma_temporal"], R["diffusion"]
+    A, T, Fd, hh = SHAPES[name]
+    act = 1 if discrete else {"spread": 5, "tag": 5, "ant": 2, "smac": 1}[name]
+    nact = 14 if discrete else 0
+    net = quiet(M.SharedConvAttentionDeconv, horizon=T, transition_dim=Fd, dim=width, history_horizon=hh,
+                dim_mults=(1, 4, 8), n_agents=A, returns_condition=True, condition_dropout=0.25)
+    dif = quiet(D.GaussianDiffusion, net, n_agents=A, horizon=T - hh, history_horizon=hh, observation_dim=Fd,
+                action_dim=act, discrete_action=discrete, num_actions=nact, n_timesteps=K,
+                returns_condition=True, condition_guidance_w=1.2, hidden_dim=64 if width < 128 else 256,
+                share_inv=share_inv, clip_denoised=True, predict_epsilon=True, loss_discount=1.0)
+    fill_closed_form(dif)
+    return dif, (A, T, Fd, hh, act, nact)
+
+
+def gen_loss(R):
+    out = {}
+    for tag, name, discrete, share in (("spread", "spread", False, True), ("ant", "ant", False, True),
+                                       ("smac", "smac", True, True), ("spread_indep", "spread", False, False)):
+        dif, (A, T, Fd, hh, act, nact) = build_diffusion(R, name, 16, 200, discrete, share)
+        vis = np.ones(A, dtype=bool)
+        if hh > 0:
+            vis[-1] = False
+        batch = O.synthetic_batch(3, T, A, Fd, act, hh, discrete, nact, seed=11, visible=vis)
+        with Recorder() as rec:
+            loss, info = dif.loss(**batch)
+            loss.backward()
+        out[f"{tag}.t"] = rec.of("randint")[0]
+        out[f"{tag}.noise"] = rec.of("randn_like")[0]
+        out[f"{tag}.dropout_mask"] = rec.of("bern")[0]
+        out[f"{tag}.loss"] = loss.detach()
+        for k, v in info.items():
+            out[f"{tag}.info.{k}"] = torch.as_tensor(v).detach()
+        out[f"{tag}.visible"] = vis
+        out[f"{tag}.loss_weights"] = dif.loss_fn.weights
+        names, rows = grad_digest([(k, p.grad) for k, p in dif.named_parameters() if p.grad is not None])
+        out[f"{tag}.gp_names"] = names
+        out[f"{tag}.gp_digest"] = rows
+        for k in ("inv_model.4.bias", "model.net.final_conv.1.bias", "inv_model.0.4.bias"):
+            pd = dict(dif.named_parameters())
+            if k in pd:
+                out[f"{tag}.gp.{k}"] = pd[k].grad
+    save("g4_loss", **out)
+
+
+def gen_sample(R):
+    out = {}
+    for tag, name, width, K, B in (("small_k200", "spread", 16, 200, 2), ("smac_k20", "smac", 16, 20, 2),
+                                   ("full_k8", "spread", 128, 8, 2)):
+        dif, (A, T, Fd, hh, act, nact) = build_diffusion(R, name, width, K)
+        vis = np.ones(A, dtype=bool)
+        batch = O.synthetic_batch(B, T, A, Fd, act, hh, False, 0, seed=5, visible=vis)
+        cond, returns = batch["cond"], batch["returns"]
+        # draw 0 = initial x_K (tempered by 0.5, diffusion.py:239), draws 1..K-1 = posterior z (none at t == 0);
+        # they are closed_form_normal(f"{tag}.{i}", shape) so the fixture need not store them.
+        with Recorder(closed_form_randn=tag) as rec:
+            x, chain = dif.conditional_sample(cond, returns=returns, verbose=False, return_diffusion=True)
+        assert len(rec.of("randn")) == K
+        out[f"{tag}.x"] = x
+        sel = [0, 1, K // 2, K - 1, K]
+        out[f"{tag}.chain_idx"] = np.array(sel)
+        out[f"{tag}.chain"] = chain[:, sel]
+        out[f"{tag}.cond_x"] = cond["x"]
+        out[f"{tag}.cond_masks"] = cond["masks"]
+        out[f"{tag}.returns"] = returns
+        if tag == "small_k200":
+            dif.set_ddim_scheduler(15)
+            with Recorder(closed_form_randn="ddim15") as rec:
+                xd = dif.conditional_sample(cond, returns=returns, verbose=False)
+            assert len(rec.of("randn")) == 1
+            out["ddim15.x"] = xd
+    save("g6_sample", **out)
+
+
+def main():
+    torch.manual_seed(1234)
+    torch.set_num_threads(8)
+    R = load_reference()
+    gen_modules(R)
+    gen_denoiser(R, 16, ["spread", "tag", "ant", "smac"], "g2_denoiser_w16", True)
+    gen_denoiser(R, 128, ["spread"], "g3_denoiser_w128", False)
+    gen_loss(R)
+    gen_sample(R)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+"""Pin the CPU oracle against golden vectors captured from the reference's own modules.
+
+The fixtures were produced by oracle/gen_golden.py (it imports /root/reference's model files under
+stubs); this test needs only tests/golden and runs without a GPU.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import madiff_oracle as O
+
+SHAPES = {"spread": (3, 24, 18, 0), "tag": (3, 24, 16, 0), "ant": (4, 28, 54, 18), "smac": (8, 24, 88, 20)}
+TOL = 2e-6  # same fp32 arithmetic on the same CPU, different op grouping only
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def den_cfg(name, width):
+    A, Tt, Fd, hh = SHAPES[name]
+    return O.DenoiserCfg(horizon=Tt, transition_dim=Fd, dim=width, history_horizon=hh, dim_mults=(1, 4, 8),
+                         n_agents=A, returns_condition=True, condition_dropout=0.25)
+
+
+def dif_cfg(name, K, discrete=False, share_inv=True, hidden=64):
+    A, Tt, Fd, hh = SHAPES[name]
+    act = 1 if discrete else {"spread": 5, "tag": 5, "ant": 2, "smac": 1}[name]
+    return O.DiffusionCfg(n_agents=A, horizon=Tt - hh, history_horizon=hh, observation_dim=Fd, action_dim=act,
+                          n_timesteps=K, discrete_action=discrete, num_actions=14 if discrete else 0,
+                          hidden_dim=hidden, returns_condition=True, condition_guidance_w=1.2, share_inv=share_inv)
+
+
+def full_params(dcfg, c):
+    den = O.closed_form_state({"model." + k: v for k, v in O.denoiser_param_shapes(dcfg).items()})
+    inv = O.closed_form_state(O.inv_param_shapes(c))
+    return {**den, **inv}
+
+
+def test_posemb(golden):
+    g = golden("g1_modules")
+    y = O.sinusoidal_embedding(T(g["posemb.t"]), 32)
+    assert rel_err(y, g["posemb.y"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag,key", [("cblock", "cblock"), ("rtb_proj", "rtb_proj"), ("rtb_same", "rtb_same")])
+def test_leaf_blocks(golden, tag, key):
+    g = golden("g1_modules")
+    names = [k[len(tag) + 4:] for k in g if k.startswith(tag + ".gp.")]
+    p = {key + "." + n: O.closed_form_param(key + "." + n, g[f"{tag}.gp.{n}"].shape) for n in names}
+    x = T(g[tag + ".in0"])
+    if tag == "cblock":
+        y = O.conv_gn_mish(p, key, x)
+    else:
+        y = O.residual_block(p, key, x, T(g[tag + ".in1"]))
+    assert rel_err(y, g[tag + ".y"]) < TOL
+
+
+def test_attention_leaf(golden):
+    g = golden("g1_modules")
+    names = [k[len("attn.gp."):] for k in g if k.startswith("attn.gp.")]
+    p = {"attn." + n: O.closed_form_param("attn." + n, g[f"attn.gp.{n}"].shape) for n in names}
+    y = O.agent_attention(p, "attn", T(g["attn.in0"]), T(g["attn.in1"]))
+    assert rel_err(y, g["attn.y"]) < TOL
+    assert float(np.abs(g["attn.y"] - g["attn.in0"]).max()) > 1e-2  # gamma != 0: the layer is not an identity
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_denoiser_small(golden, name):
+    g = golden("g2_denoiser_w16")
+    cfg = den_cfg(name, 16)
+    p = O.closed_form_state({"model." + k: v for k, v in O.denoiser_param_shapes(cfg).items()})
+    p = {k[len("model."):]: v for k, v in p.items()}
+    x, t, r = T(g[name + ".x"]), T(g[name + ".t"]), T(g[name + ".returns"])
+    assert rel_err(O.denoiser_forward(p, cfg, x, t, r), g[name + ".y_cond"]) < TOL
+    assert rel_err(O.denoiser_forward(p, cfg, x, t, r, None, True), g[name + ".y_uncond"]) < TOL
+    assert rel_err(O.denoiser_forward(p, cfg, x, t, r, T(g[name + ".dropout_mask"])), g[name + ".y_drop"]) < TOL
+    # gradients (autograd through the oracle) against the reference's digests
+    pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xg = x.clone().requires_grad_(True)
+    y = O.denoiser_forward(pg, cfg, xg, t, r, T(g[name + ".dropout_mask"]))
+    y.backward(T(g[name + ".gy"]))
+    assert rel_err(xg.grad, g[name + ".gx"]) < 1e-5
+    dig = {n: row for n, row in zip(g[name + ".gp_names"], g[name + ".gp_digest"])}
+    for n in g[name + ".nograd_names"]:
+        assert pg[str(n)].grad is None and str(n).startswith("self_attn.3.")
+    worst = 0.0
+    for n, row in dig.items():
+        gr = pg[str(n)].grad.double()
+        # key biases have an analytically ZERO gradient (softmax shift invariance): allow fp32 noise
+        worst = max(worst, abs(gr.pow(2).sum().sqrt().item() - row[2]) / max(row[2], 2e-2))
+    assert worst < 5e-4, worst   # gradients: fp32 vs fp32 with different op grouping (outputs are held to TOL)
+    for k in g:
+        if k.startswith(name + ".gp.") :
+            assert rel_err(pg[k[len(name) + 4:]].grad, g[k]) < 2e-5, k
+
+
+def test_denoiser_full_width(golden):
+    g = golden("g3_denoiser_w128")
+    cfg = den_cfg("spread", 128)
+    shapes = O.denoiser_param_shapes(cfg)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 64342550  # 64.34 M parameters
+    p = {k: O.closed_form_param("model." + k, s) for k, s in shapes.items()}
+    x, t, r = T(g["spread.x"]), T(g["spread.t"]), T(g["spread.returns"])
+    assert rel_err(O.denoiser_forward(p, cfg, x, t, r), g["spread.y_cond"]) < 5e-6
+    assert rel_err(O.denoiser_forward(p, cfg, x, t, r, None, True), g["spread.y_uncond"]) < 5e-6
+
+
+@pytest.mark.parametrize("tag,name,discrete,share", [("spread", "spread", False, True), ("ant", "ant", False, True),
+                                                      ("smac", "smac", True, True),
+                                                      ("spread_indep", "spread", False, False)])
+def test_loss(golden, tag, name, discrete, share):
+    g = golden("g4_loss")
+    A, Tt, Fd, hh = SHAPES[name]
+    dcfg, c = den_cfg(name, 16), dif_cfg(name, 200, discrete, share)
+    p = full_params(dcfg, c)
+    batch = O.synthetic_batch(3, Tt, A, Fd, c.action_dim, hh, discrete, c.num_actions, seed=11, visible=g[tag + ".visible"])
+    assert rel_err(O.loss_weights(c), g[tag + ".loss_weights"]) == 0.0
+    pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss, info, _ = O.diffusion_loss(pg, dcfg, c, O.DDPMSchedule(200), batch["x"], batch["cond"], batch["loss_masks"],
+                                     T(g[tag + ".t"]), T(g[tag + ".noise"]), batch["returns"],
+                                     T(g[tag + ".dropout_mask"]), batch.get("legal_actions"))
+    assert loss.dtype == torch.float64                       # loss_masks is float64 (sequence.py:314)
+    assert abs(loss.item() - float(g[tag + ".loss"])) < 2e-6 * abs(float(g[tag + ".loss"]))
+    for k in ("a0_loss", "inv_loss", "inv_acc"):
+        if f"{tag}.info.{k}" in g:
+            assert abs(float(info[k]) - float(g[f"{tag}.info.{k}"])) <= 2e-6 * abs(float(g[f"{tag}.info.{k}"])) + 1e-12, k
+    loss.backward()
+    for n, row in zip(g[tag + ".gp_names"], g[tag + ".gp_digest"]):
+        gr = pg[str(n)].grad.double()
+        assert abs(gr.pow(2).sum().sqrt().item() - row[2]) <= 5e-4 * row[2] + 2e-6, n
+
+
+@pytest.mark.parametrize("tag,name,width,K", [("small_k200", "spread", 16, 200), ("smac_k20", "smac", 16, 20),
+                                               ("full_k8", "spread", 128, 8)])
+def test_sampling(golden, tag, name, width, K):
+    g = golden("g6_sample")
+    A, Tt, Fd, hh = SHAPES[name]
+    dcfg, c = den_cfg(name, width), dif_cfg(name, K, hidden=64 if width < 128 else 256)
+    p = full_params(dcfg, c)
+    shape = (2, Tt, A, Fd)
+    x_init = 0.5 * T(O.closed_form_normal(f"{tag}.0", shape))
+    z = [T(O.closed_form_normal(f"{tag}.{i}", shape)) for i in range(1, K)]
+    cond = {"x": T(g[tag + ".cond_x"]), "masks": T(g[tag + ".cond_masks"])}
+    with torch.no_grad():
+        x, chain = O.conditional_sample(p, dcfg, c, O.DDPMSchedule(K), cond, T(g[tag + ".returns"]), x_init, z, True)
+    sel = g[tag + ".chain_idx"]
+    assert rel_err(chain[:, sel], g[tag + ".chain"]) < 1e-4
+    assert rel_err(x, g[tag + ".x"]) < 1e-4
+    m = g[tag + ".cond_masks"]
+    assert np.array_equal(x.numpy()[m], g[tag + ".cond_x"][m])   # inpainting exactly enforced
+
+
+def test_ddim(golden):
+    g = golden("g6_sample")
+    tag = "small_k200"
+    A, Tt, Fd, hh = SHAPES["spread"]
+    dcfg, c = den_cfg("spread", 16), dif_cfg("spread", 200)
+    p = full_params(dcfg, c)
+    x_init = 0.5 * T(O.closed_form_normal("ddim15.0", (2, Tt, A, Fd)))
+    cond = {"x": T(g[tag + ".cond_x"]), "masks": T(g[tag + ".cond_masks"])}
+    with torch.no_grad():
+        x = O.conditional_sample(p, dcfg, c, O.DDIMSchedule(200, 15), cond, T(g[tag + ".returns"]), x_init, [])
+    assert rel_err(x, g["ddim15.x"]) < 1e-4
