@@ -1,0 +1,14 @@
+from madiff_amd.diffusion import Encoder, IdentityEncoder  # noqa: F401
+from madiff_amd.host import (  # noqa: F401
+    Config,
+    Progress,
+    Silent,
+    apply_dict,
+    batch_to_device,
+    batchify,
+    import_class,
+    set_seed,
+    to_device,
+    to_np,
+    to_torch,
+)

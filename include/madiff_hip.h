@@ -1,0 +1,126 @@
+/* madiff_hip.h - C ABI of libmadiff_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary of the MADiff hot path.  The reference (zbzhu99/madiff) is pure Python/PyTorch and has
+ * no FFI of its own; what these entry points replace are the stock ATen/cuDNN ops reached from the reference
+ * files cited on each declaration (paths relative to the reference repository root).  They are bound with
+ * ctypes by madiff_amd/lib.py and called only from the torch.autograd.Functions in madiff_amd/ops.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch allocation), 16-byte aligned;
+ *   - dtype: MADIFF_F32 (0) = fp32 storage + exact-fp32 MFMA, MADIFF_BF16 (1) = bf16 storage + bf16 MFMA with
+ *     fp32 accumulation; statistics, softmax, losses, the posterior and all parameter gradients are fp32;
+ *   - activations are channels-last matrices [rows = (sequence n, time t), cols = channels], leading dimension
+ *     `ld*` in elements, column counts padded with zeros to a multiple of 32;
+ *   - trajectories keep the reference layout [B, T, A, F] in fp32;
+ *   - return value: 0 = ok, -1 = invalid argument (nothing launched), otherwise a hipError_t; never throws;
+ *   - `stream` is a hipStream_t; every call is asynchronous on it and none allocates, frees or synchronises,
+ *     so a caller may capture any sequence of them into a hipGraph.
+ */
+#ifndef MADIFF_HIP_H
+#define MADIFF_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MADIFF_F32 0
+#define MADIFF_BF16 1
+
+typedef void* madiff_stream_t; /* hipStream_t */
+
+int madiff_version(void);
+const char* madiff_arch(void);
+
+/* Implicit-GEMM convolution / linear:
+ *   C[m, o] = act( sum_{tap, c} X[src(m, tap), c] * W[o, tap*Cin + c] + bias[o] + rowbias[m / T_out, o] )
+ * src(m = (n, t), tap): tr == 0: t_in = t*stride + tap - pad;  tr == 1: t_in = (t + pad - tap) / stride when divisible;
+ * rows outside [0, T_in) contribute zeros.  Channels [0, Csplit) come from X, [Csplit, Cin) from X2 (skip concat).
+ * Replaces nn.Conv1d(k=5) of Conv1dBlock (diffuser/models/helpers.py:63-66), Downsample1d/Upsample1d
+ * (helpers.py:32-47), the 1x1 residual / Q,K,V convs (models/temporal.py:70-72,183-187), every nn.Linear
+ * (temporal.py:74-88,177-181,231-251; models/diffusion.py:111-119) and their data gradients.
+ * act: 0 none, 1 relu, 2 mish.  permA > 0 stores rows (b, a, t) as (b, t, a) (the "b a f t -> b t a f" of
+ * models/ma_temporal.py:416).  out_f32 != 0 writes fp32 output in the bf16 build. */
+int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, const void* X2, int ldx2, int Csplit, int M, int Cin,
+                    int taps, int T_out, int T_in, int stride, int pad, int tr, const void* W, int ldw, int Nout, int Npad,
+                    const float* bias, const float* rowbias, int ldrb, void* C, int ldc, int act, int permT, int permA,
+                    madiff_stream_t stream);
+
+/* Weight gradient of the above: dW[o, tap*Cin + c] = sum_m dY[m, o] * X[src(m, tap), c]  (fp32 output).
+ * Replaces the wgrad half of autograd for the same modules. */
+int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,
+                      int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,
+                      int ldw, int Nout, madiff_stream_t stream);
+
+/* Parameter layout (fp32, element (o, i, tap) at o*so + i*si + tap*st) <-> GEMM layout [O, taps, Ipad].
+ * pack writes dst[(o*taps + tap)*dst_ld + dst_off + i] and leaves pad columns alone (buffer is zero-filled once). */
+int madiff_pack_weight(int dtype, const float* src, void* dst, int O, int I, int taps, long so, long si, long st,
+                       int dst_ld, int dst_off, madiff_stream_t stream);
+int madiff_unpack_wgrad(const float* packed, float* grad, int O, int I, int Ipad, int taps, long so, long si, long st,
+                        madiff_stream_t stream);
+
+/* Fused GroupNorm(G) + Mish + {mode 1: + rowbias[n, c] (timestep embedding), mode 2: + res[m, c] (residual)}.
+ * Replaces helpers.py:67-71 plus the adds of temporal.py:197-200.  mean/rstd [N, G] are saved for backward. */
+int madiff_gn_mish_fwd(int dtype, const void* y, int ldy, void* out, int ldo, const float* gamma, const float* beta,
+                       float* mean, float* rstd, int N, int T, int C, int Cpad, int G, float eps, int mode,
+                       const float* rowbias, int ldrb, const void* res, int ldr, madiff_stream_t stream);
+/* Backward of the above.  dgamma/dbeta [C] are accumulated (caller zeroes); drowbias [N, ldrb] may be null. */
+int madiff_gn_mish_bwd(int dtype, const void* y, int ldy, const void* dout, int ldd, void* dy, int ldg, const float* gamma,
+                       const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                       float* drowbias, int ldrb, int N, int T, int C, int Cpad, int G, madiff_stream_t stream);
+
+/* Cross-agent attention core on the fused projection matrix qkv = [q | k | v] ([M, 2*Cq + C]):
+ * softmax_a2(q.k / sqrt(d_qk*T)) . v, then x + gamma*out.  Replaces temporal.py:104-124. */
+int madiff_attn_fwd(int dtype, const void* qkv, int ldq, const void* x, int ldx, void* out, int ldo, const float* gamma,
+                    int B, int A, int T, int H, int Cq, int C, int residual, madiff_stream_t stream);
+int madiff_attn_bwd(int dtype, const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg, const float* gamma,
+                    float* dgamma, int B, int A, int T, int H, int Cq, int C, int residual, madiff_stream_t stream);
+
+/* [B,T,A,F] fp32 -> [(b a), t, Fpad] storage type, optionally fused with add_noise (diffusers DDPMScheduler.add_noise,
+ * called at models/diffusion.py:292) and inpainting (helpers.py:194-196, diffusion.py:293).  x_noisy (fp32, may be null)
+ * receives the noised + inpainted trajectory in the reference layout. */
+int madiff_pack_input(int dtype, const float* x, const float* noise, const long* tsteps, const float* sqrt_ac,
+                      const float* sqrt_1mac, const float* cond, const uint8_t* mask, void* out, float* x_noisy, int B,
+                      int T, int A, int F, int Fpad, madiff_stream_t stream);
+int madiff_unpack_output(int dtype, const void* in, int ld, float* out, int B, int T, int A, int F, madiff_stream_t stream);
+
+/* Fused posterior step: guidance blend eps_u + w (eps_c - eps_u) (diffusion.py:203-205), x0-predict, clip to [-1,1],
+ * posterior mean, + sigma*z (diffusers DDPMScheduler.step / DDIMScheduler.step, called at diffusion.py:261) and the
+ * inpainting of the next iteration (diffusion.py:251,268).  coef: [n_steps, 6] rows {sqrt(1-abar), 1/sqrt(abar), c_x0,
+ * c_xt, c_eps, sigma}; the row index is read from *step_ptr on the device (hipGraph replay) or taken from step_val. */
+int madiff_posterior_step(const float* x, const float* eps_c, const float* eps_u, float w, const float* z, const float* cond,
+                          const uint8_t* mask, const float* coef, const int* step_ptr, int step_val, float* out, long total,
+                          madiff_stream_t stream);
+int madiff_inpaint(float* x, const float* cond, const uint8_t* mask, long total, madiff_stream_t stream);
+/* Device-side step counter of the captured sampling loop (replaces the host loop variable of diffusion.py:249-255). */
+int madiff_sampler_fill_time(const int* state, const long* tsteps, long* ts_out, int B, madiff_stream_t stream);
+int madiff_sampler_advance(int* state, madiff_stream_t stream);
+
+/* Masked weighted state loss (helpers.py:243-250, diffusion.py:328-330): per-sample sums
+ * {sum (p-q)^2 w m, sum m, sum (p-q)^2 w} and its gradient w.r.t. p. */
+int madiff_mse_fwd(const float* pred, const float* targ, const float* w, const float* mask, float* sums, int B, int TA,
+                   int F, madiff_stream_t stream);
+int madiff_mse_bwd(const float* pred, const float* targ, const float* w, const float* mask, const float* sums,
+                   const float* go, float* dpred, int B, int TA, int F, madiff_stream_t stream);
+
+/* SinusoidalPosEmb (helpers.py:17-29) for timesteps ts[B], repeated over A agents: out [B*A, ld], cols >= 2*half zeroed. */
+int madiff_sinusoid(int dtype, const long* ts, const float* freq, void* out, int ld, int B, int A, int half,
+                    madiff_stream_t stream);
+
+/* nn.Mish (kind 2) / nn.ReLU (kind 1) on flat padded matrices, forward and backward. */
+int madiff_act_fwd(int dtype, int kind, const void* x, void* y, long n, madiff_stream_t stream);
+int madiff_act_bwd(int dtype, int kind, const void* ref, const void* dy, void* dx, long n, madiff_stream_t stream);
+
+/* Bias gradients: out[c] += sum_m x[m, c] (caller zeroes) and per-sequence sums out[n, c] = sum_t x[(n,t), c]. */
+int madiff_colsum(int dtype, const void* x, int ld, float* out, long M, int C, madiff_stream_t stream);
+int madiff_seqsum(int dtype, const void* x, int ld, float* out, int ldo, long N, int T, int C, madiff_stream_t stream);
+
+/* Fused Adam (torch.optim.Adam defaults, diffuser/utils/training.py:109,154) + EMA (training.py:20-39) over one flat
+ * fp32 tensor.  do_ema: 0 none, 1 lerp with ema_beta, 2 copy. */
+int madiff_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
+                    float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta,
+                    madiff_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,374 @@
+// Bandwidth-bound kernels of the diffusion wrapper: layout pack/unpack (+ fused add_noise + inpainting),
+// the fused DDPM/DDIM posterior step (guidance blend + x0-predict + clip + posterior mean + noise +
+// inpainting), the masked weighted MSE (forward sums and backward), small activations and reductions.
+// Trajectory tensors keep the reference layout [B, T, A, F] in fp32; the denoiser's internal layout is
+// [(b a), t, Fpad] in the build's storage type.
+#include "common.h"
+
+// ---------------------------------------------------------------- pack: [B,T,A,F] f32 -> [(b a) t Fpad]
+// optional add_noise (diffusers DDPMScheduler.add_noise, called at diffusion.py:292) and inpainting
+// (helpers.py:194-196) fused in.
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                  const long* __restrict__ tsteps, const float* __restrict__ sqrt_ac,
+                                  const float* __restrict__ sqrt_1mac, const float* __restrict__ cond,
+                                  const uint8_t* __restrict__ mask, T* __restrict__ out, float* __restrict__ x_noisy,
+                                  int B, int Tn, int A, int F, int Fpad) {
+  const long total = (long)B * A * Tn * Fpad;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int f = e % Fpad;
+    long r = e / Fpad;
+    int t = r % Tn;
+    long ba = r / Tn;
+    int a = ba % A;
+    int b = ba / A;
+    float v = 0.f;
+    if (f < F) {
+      long src = (((long)b * Tn + t) * A + a) * F + f;
+      v = x[src];
+      if (noise) {
+        long ts = tsteps[b];
+        v = sqrt_ac[ts] * v + sqrt_1mac[ts] * noise[src];
+      }
+      if (mask && mask[src]) v = cond[src];
+      if (x_noisy) x_noisy[src] = v;
+    }
+    out[e] = from_f32<T>(v);
+  }
+}
+
+// unpack: [(b a) t ld] -> [B,T,A,F] f32
+template <typename T>
+__global__ void unpack_output_kernel(const T* __restrict__ in, int ld, float* __restrict__ out, int B, int Tn, int A,
+                                     int F) {
+  const long total = (long)B * Tn * A * F;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int f = e % F;
+    long r = e / F;
+    int a = r % A;
+    long bt = r / A;
+    int t = bt % Tn;
+    int b = bt / Tn;
+    out[e] = to_f32(in[(((long)b * A + a) * Tn + t) * ld + f]);
+  }
+}
+
+// ---------------------------------------------------------------- posterior step
+// coef row i: {sqrt(1-abar_t), 1/sqrt(abar_t), c_x0, c_xt, c_eps, sigma}.  DDPM: c_eps = 0; DDIM (eta=0):
+// c_xt = 0, c_eps = sqrt(1-abar_prev), sigma = 0.  x0 is always clipped to [-1, 1] (clip_sample=True).
+__global__ void posterior_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
+                                      const float* __restrict__ eps_u, float w, const float* __restrict__ z,
+                                      const float* __restrict__ cond, const uint8_t* __restrict__ mask,
+                                      const float* __restrict__ coef, const int* __restrict__ step_ptr, int step_val,
+                                      float* __restrict__ out, long total) {
+  const int i = step_ptr ? step_ptr[0] : step_val;
+  const float sb = coef[i * 6 + 0], isa = coef[i * 6 + 1], c0 = coef[i * 6 + 2], ct = coef[i * 6 + 3],
+              ce = coef[i * 6 + 4], sg = coef[i * 6 + 5];
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    float xv = x[e];
+    float ec = eps_c[e];
+    float ep = eps_u ? (eps_u[e] + w * (ec - eps_u[e])) : ec;
+    float x0 = (xv - sb * ep) * isa;
+    x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    float v = c0 * x0 + ct * xv + ce * ep;
+    if (sg != 0.f) v += sg * z[e];
+    if (mask && mask[e]) v = cond[e];   // inpainting of the NEXT iteration / final enforcement
+    out[e] = v;
+  }
+}
+
+__global__ void inpaint_kernel(float* __restrict__ x, const float* __restrict__ cond, const uint8_t* __restrict__ mask,
+                               long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    if (mask[e]) x[e] = cond[e];
+}
+
+// sampler state: state[0] = step index.  fill: ts_out[b] = tsteps[state[0]]; advance: state[0] += 1.
+__global__ void sampler_fill_time_kernel(const int* __restrict__ state, const long* __restrict__ tsteps,
+                                         long* __restrict__ ts_out, int B) {
+  long t = tsteps[state[0]];
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) ts_out[b] = t;
+}
+__global__ void sampler_advance_kernel(int* state) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1;
+}
+
+// ---------------------------------------------------------------- masked weighted MSE (helpers.py:243-250 + diffusion.py:328-330)
+// sums[b] = { sum_{t,a,f} (p-q)^2 w m , sum_{t,a} m , sum_{t,a,f} (p-q)^2 w }
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ targ,
+                                                      const float* __restrict__ w, const float* __restrict__ mask,
+                                                      float* __restrict__ sums, int TA, int F) {
+  __shared__ float red[3][4];
+  const int b = blockIdx.x;
+  const long base = (long)b * TA * F;
+  float s = 0.f, u = 0.f, ms = 0.f;
+  for (int i = threadIdx.x; i < TA * F; i += 256) {
+    float d = pred[base + i] - targ[base + i];
+    float l = d * d * w[i];
+    u += l;
+    s += l * mask[(long)b * TA + i / F];
+  }
+  for (int i = threadIdx.x; i < TA; i += 256) ms += mask[(long)b * TA + i];
+  s = wave_sum(s); u = wave_sum(u); ms = wave_sum(ms);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = ms; red[2][wave] = u; }
+  __syncthreads();
+  if (threadIdx.x < 3) sums[b * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// d pred = go * 2 (p - q) w m / (B F sum_m[b])
+__global__ void mse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ targ,
+                               const float* __restrict__ w, const float* __restrict__ mask,
+                               const float* __restrict__ sums, const float* __restrict__ go, float* __restrict__ dpred,
+                               int B, int TA, int F) {
+  const long total = (long)B * TA * F;
+  const float g = go[0] * 2.f / ((float)B * (float)F);
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int b = e / ((long)TA * F);
+    int i = e - (long)b * TA * F;
+    float m = mask[(long)b * TA + i / F];
+    dpred[e] = g * (pred[e] - targ[e]) * w[i] * m / sums[b * 3 + 1];
+  }
+}
+
+// ---------------------------------------------------------------- sinusoidal timestep embedding (helpers.py:17-29)
+template <typename T>
+__global__ void sinusoid_kernel(const long* __restrict__ ts, const float* __restrict__ freq, T* __restrict__ out,
+                                int ld, int B, int A, int half) {
+  const long total = (long)B * A * ld;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int j = e % ld;
+    int b = (e / ld) / A;
+    float v = 0.f;
+    if (j < 2 * half) {
+      float arg = (float)ts[b] * freq[j < half ? j : j - half];
+      v = j < half ? sinf(arg) : cosf(arg);
+    }
+    out[e] = from_f32<T>(v);
+  }
+}
+
+// ---------------------------------------------------------------- activations on flat (padded) matrices
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n, int kind) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    float v = to_f32(x[e]);
+    y[e] = from_f32<T>(kind == 2 ? mish_f(v) : fmaxf(v, 0.f));
+  }
+}
+// kind 2 (mish): ref = pre-activation.  kind 1 (relu): ref = output (or pre-activation; same sign test).
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ ref, const T* __restrict__ dy, T* __restrict__ dx, long n, int kind) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    float v = to_f32(ref[e]), g = to_f32(dy[e]);
+    dx[e] = from_f32<T>(kind == 2 ? g * mish_grad_f(v) : (v > 0.f ? g : 0.f));
+  }
+}
+
+// ---------------------------------------------------------------- reductions for bias / row-bias gradients
+// colsum: out[c] += sum_m x[m, c]  (caller zeroes out).  grid = (ceil(C/64), row blocks); block 64x4.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, long M, int C) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ry = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (long m = (long)blockIdx.y * 4 + ry; m < M; m += (long)gridDim.y * 4) s += to_f32(x[m * ld + c]);
+  red[ry][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// seqsum: out[n, c] = sum_t x[(n, t), c]
+template <typename T>
+__global__ void seqsum_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, int ldo, long N, int Tn, int C) {
+  const long total = N * C;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    long n = e / C;
+    int c = e - n * C;
+    float s = 0.f;
+    for (int t = 0; t < Tn; t++) s += to_f32(x[(n * Tn + t) * ld + c]);
+    out[n * ldo + c] = s;
+  }
+}
+
+// ---------------------------------------------------------------- fused Adam + EMA over one flat tensor
+// torch.optim.Adam defaults (training.py:109): no weight decay, no amsgrad.  EMA (training.py:20-39):
+// ema = beta*ema + (1-beta)*p when do_ema == 1, ema = p when do_ema == 2 (the "copy until step 2000" phase).
+__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, float* __restrict__ ema, long n, float lr, float b1, float b2,
+                                float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    float gr = g[e] * grad_scale;
+    float mm = b1 * m[e] + (1.f - b1) * gr;
+    float vv = b2 * v[e] + (1.f - b2) * gr * gr;
+    m[e] = mm;
+    v[e] = vv;
+    float denom = sqrtf(vv) / bc2_sqrt + eps;
+    float pv = p[e] - (lr / bc1) * (mm / denom);
+    p[e] = pv;
+    if (do_ema == 1) ema[e] = ema_beta * ema[e] + (1.f - ema_beta) * pv;
+    else if (do_ema == 2) ema[e] = pv;
+  }
+}
+
+static inline int nblocks(long total, int per = 256, int cap = 4096) {
+  long b = (total + per - 1) / per;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+extern "C" int madiff_pack_input(int dtype, const float* x, const float* noise, const long* tsteps, const float* sqrt_ac,
+                                 const float* sqrt_1mac, const float* cond, const uint8_t* mask, void* out,
+                                 float* x_noisy, int B, int T, int A, int F, int Fpad, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (T <= 0 || A <= 0 || F <= 0 || Fpad < F || (noise && (!tsteps || !sqrt_ac || !sqrt_1mac)) || (mask && !cond)) return -1;
+  long total = (long)B * A * T * Fpad;
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((pack_input_kernel<bf16_t>), dim3(nblocks(total)), dim3(256), 0, stream, x, noise, tsteps, sqrt_ac,
+                       sqrt_1mac, cond, mask, (bf16_t*)out, x_noisy, B, T, A, F, Fpad);
+  else
+    hipLaunchKernelGGL((pack_input_kernel<float>), dim3(nblocks(total)), dim3(256), 0, stream, x, noise, tsteps, sqrt_ac,
+                       sqrt_1mac, cond, mask, (float*)out, x_noisy, B, T, A, F, Fpad);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_unpack_output(int dtype, const void* in, int ld, float* out, int B, int T, int A, int F,
+                                    hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (T <= 0 || A <= 0 || F <= 0 || ld < F) return -1;
+  long total = (long)B * T * A * F;
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((unpack_output_kernel<bf16_t>), dim3(nblocks(total)), dim3(256), 0, stream, (const bf16_t*)in, ld, out, B, T, A, F);
+  else
+    hipLaunchKernelGGL((unpack_output_kernel<float>), dim3(nblocks(total)), dim3(256), 0, stream, (const float*)in, ld, out, B, T, A, F);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_posterior_step(const float* x, const float* eps_c, const float* eps_u, float w, const float* z,
+                                     const float* cond, const uint8_t* mask, const float* coef, const int* step_ptr,
+                                     int step_val, float* out, long total, hipStream_t stream) {
+  if (total <= 0) return 0;
+  if (!x || !eps_c || !coef || !out || (mask && !cond) || (!step_ptr && step_val < 0)) return -1;
+  hipLaunchKernelGGL(posterior_step_kernel, dim3(nblocks(total)), dim3(256), 0, stream, x, eps_c, eps_u, w, z, cond, mask,
+                     coef, step_ptr, step_val, out, total);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_inpaint(float* x, const float* cond, const uint8_t* mask, long total, hipStream_t stream) {
+  if (total <= 0) return 0;
+  if (!x || !cond || !mask) return -1;
+  hipLaunchKernelGGL(inpaint_kernel, dim3(nblocks(total)), dim3(256), 0, stream, x, cond, mask, total);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_sampler_fill_time(const int* state, const long* tsteps, long* ts_out, int B, hipStream_t stream) {
+  if (B <= 0 || !state || !tsteps || !ts_out) return -1;
+  hipLaunchKernelGGL(sampler_fill_time_kernel, dim3(nblocks(B)), dim3(256), 0, stream, state, tsteps, ts_out, B);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_sampler_advance(int* state, hipStream_t stream) {
+  if (!state) return -1;
+  hipLaunchKernelGGL(sampler_advance_kernel, dim3(1), dim3(64), 0, stream, state);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_mse_fwd(const float* pred, const float* targ, const float* w, const float* mask, float* sums,
+                              int B, int TA, int F, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (TA <= 0 || F <= 0) return -1;
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3(B), dim3(256), 0, stream, pred, targ, w, mask, sums, TA, F);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_mse_bwd(const float* pred, const float* targ, const float* w, const float* mask, const float* sums,
+                              const float* go, float* dpred, int B, int TA, int F, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (TA <= 0 || F <= 0) return -1;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(nblocks((long)B * TA * F)), dim3(256), 0, stream, pred, targ, w, mask, sums, go,
+                     dpred, B, TA, F);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_sinusoid(int dtype, const long* ts, const float* freq, void* out, int ld, int B, int A, int half,
+                               hipStream_t stream) {
+  if (B <= 0 || A <= 0 || half <= 0 || ld < 2 * half) return -1;
+  long total = (long)B * A * ld;
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((sinusoid_kernel<bf16_t>), dim3(nblocks(total)), dim3(256), 0, stream, ts, freq, (bf16_t*)out, ld, B, A, half);
+  else
+    hipLaunchKernelGGL((sinusoid_kernel<float>), dim3(nblocks(total)), dim3(256), 0, stream, ts, freq, (float*)out, ld, B, A, half);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_act_fwd(int dtype, int kind, const void* x, void* y, long n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (kind != 1 && kind != 2) return -1;
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((act_fwd_kernel<bf16_t>), dim3(nblocks(n)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, n, kind);
+  else
+    hipLaunchKernelGGL((act_fwd_kernel<float>), dim3(nblocks(n)), dim3(256), 0, stream, (const float*)x, (float*)y, n, kind);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_act_bwd(int dtype, int kind, const void* ref, const void* dy, void* dx, long n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (kind != 1 && kind != 2) return -1;
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), dim3(nblocks(n)), dim3(256), 0, stream, (const bf16_t*)ref, (const bf16_t*)dy, (bf16_t*)dx, n, kind);
+  else
+    hipLaunchKernelGGL((act_bwd_kernel<float>), dim3(nblocks(n)), dim3(256), 0, stream, (const float*)ref, (const float*)dy, (float*)dx, n, kind);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_colsum(int dtype, const void* x, int ld, float* out, long M, int C, hipStream_t stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (ld < C) return -1;
+  int rb = (int)((M + 255) / 256);
+  if (rb > 64) rb = 64;
+  if (rb < 1) rb = 1;
+  dim3 grid((C + 63) / 64, rb);
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x, ld, out, M, C);
+  else
+    hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ld, out, M, C);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_seqsum(int dtype, const void* x, int ld, float* out, int ldo, long N, int T, int C, hipStream_t stream) {
+  if (N <= 0 || C <= 0) return 0;
+  if (ld < C || ldo < C || T <= 0) return -1;
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((seqsum_kernel<bf16_t>), dim3(nblocks(N * C)), dim3(256), 0, stream, (const bf16_t*)x, ld, out, ldo, N, T, C);
+  else
+    hipLaunchKernelGGL((seqsum_kernel<float>), dim3(nblocks(N * C)), dim3(256), 0, stream, (const float*)x, ld, out, ldo, N, T, C);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float b1,
+                               float b2, float eps, float bc1, float bc2s, float grad_scale, int do_ema,
+                               float ema_beta, hipStream_t stream) {
+  // bc1 = 1 - b1^step, bc2s = sqrt(1 - b2^step): computed by the host in double, as torch.optim.Adam does
+  if (n <= 0) return 0;
+  if (!p || !g || !m || !v || bc1 <= 0.f || bc2s <= 0.f || (do_ema && !ema)) return -1;
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(nblocks(n, 256, 8192)), dim3(256), 0, stream, p, g, m, v, ema, n, lr, b1, b2, eps,
+                     bc1, bc2s, grad_scale, do_ema, ema_beta);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_version(void) { return 1; }
+extern "C" const char* madiff_arch(void) { return "gfx950"; }

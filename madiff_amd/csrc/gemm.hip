@@ -1,0 +1,458 @@
+// Implicit-GEMM convolution / linear kernels on CDNA4 MFMA (gfx950).
+//
+// Activations are channels-last matrices [rows = (sequence n, time t), cols = channels] whose column
+// count is padded to a multiple of 32 with zeros.  One kernel family covers every dense contraction of
+// the denoiser and of the inverse-dynamics MLP:
+//
+//   gemm_fwd   C[m, o] = sum_{tap, c} X[src(m, tap), c] * W[o, tap*Cin + c]  (+bias +rowbias, act)
+//              Conv1d k5 (stride 1), Downsample k3 s2, ConvTranspose k4 s2 (tr=1), 1x1 conv, Linear,
+//              and every data-gradient (tr flips the tap direction) are all this kernel with a RowMap.
+//   gemm_wgrad dW[o, tap*Cin + c] = sum_m dY[m, o] * X[src(m, tap), c]       (fp32, split over m)
+//
+// bf16 build: __builtin_amdgcn_mfma_f32_16x16x32_bf16, fp32 accumulate.
+// fp32 build: __builtin_amdgcn_mfma_f32_16x16x4f32 (exact fp32 fmaf chain).
+// Tiles are 128x128 per 256-thread workgroup (4 waves, 64x64 each), operands staged through LDS with
+// register prefetch + double buffering; the conv taps are realised as shifted row gathers while
+// staging, so no im2col matrix ever exists in memory.
+#include "common.h"
+
+struct RowMap {
+  int T_out, T_in, stride, pad, tr;
+};
+
+struct GemmFwdParams {
+  const void* X;   int ldx;          // first source  (channels [0, Csplit))
+  const void* X2;  int ldx2;         // second source (channels [Csplit, Cin)), may be null
+  int Csplit;                        // == Cin when X2 is null
+  int M, Cin, taps;                  // M output rows; Cin padded channel count (multiple of KC)
+  RowMap rm;
+  const void* W;   int ldw;          // [Nout, taps*Cin]
+  int Nout, Npad;                    // real / padded output columns (pad columns are written as 0)
+  const float* bias;                 // [Nout] or null
+  const float* rowbias; int ldrb;    // [n_seq, ldrb] or null, row = m / T_out
+  void* C;         int ldc;
+  int act;                           // 0 none, 1 relu, 2 mish
+  int permT, permA;                  // if permA > 0: rows (b, a, t) are stored as (b, t, a)
+};
+
+template <typename T> struct MfmaTraits;
+template <> struct MfmaTraits<bf16_t> { static constexpr int KC = 32; };
+template <> struct MfmaTraits<float>  { static constexpr int KC = 16; };
+
+__device__ __forceinline__ int map_row(int n, int t, int tap, const RowMap& rm) {
+  int ti;
+  if (!rm.tr) {
+    ti = t * rm.stride + tap - rm.pad;
+    if (ti < 0 || ti >= rm.T_in) return -1;
+  } else {
+    int num = t + rm.pad - tap;
+    if (num < 0) return -1;
+    ti = num / rm.stride;
+    if (ti * rm.stride != num || ti >= rm.T_in) return -1;
+  }
+  return n * rm.T_in + ti;
+}
+
+__device__ __forceinline__ void mma_step(const bf16x8 (&a)[4], const bf16x8 (&b)[4], f32x4 (&acc)[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+}
+__device__ __forceinline__ void mma_step(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x4 (&acc)[4][4]) {
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+}
+
+template <typename T> struct FragT;
+template <> struct FragT<bf16_t> { typedef bf16x8 type; };
+template <> struct FragT<float>  { typedef f32x4 type; };
+
+#define FWD_ROWB 80  // LDS bytes per tile row: 64 B of k + 16 B pad
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmFwdParams p) {
+  constexpr int KC = MfmaTraits<T>::KC;
+  typedef typename FragT<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][256 * FWD_ROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+
+  // staging assignment: 2 A chunks + 2 W chunks (16 B each) per thread per K-step
+  int a_n[2], a_t[2], w_row[2];
+  bool a_ok[2];
+  const int kc = tid & 3;  // 16-byte chunk inside the 64-byte k-slab
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    int row = (tid >> 2) + 64 * j;
+    int m = m0 + row;
+    a_ok[j] = m < p.M;
+    int n = m / p.rm.T_out;
+    a_n[j] = n;
+    a_t[j] = m - n * p.rm.T_out;
+    w_row[j] = n0 + row;
+  }
+  const int steps_per_tap = p.Cin / KC;
+  const int nsteps = steps_per_tap * p.taps;
+
+  u32x4 ra[2], rw[2];
+  auto load_step = [&](int s) {
+    int tap = s / steps_per_tap;
+    int c0 = (s - tap * steps_per_tap) * KC;
+    const T* src = (const T*)p.X;
+    int ld = p.ldx, c = c0;
+    if (c0 >= p.Csplit) { src = (const T*)p.X2; ld = p.ldx2; c = c0 - p.Csplit; }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (a_ok[j]) {
+        int r = map_row(a_n[j], a_t[j], tap, p.rm);
+        if (r >= 0) v = *(const u32x4*)((const unsigned char*)(src + (size_t)r * ld + c) + kc * 16);
+      }
+      ra[j] = v;
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if (w_row[j] < p.Nout)
+        w = *(const u32x4*)((const unsigned char*)((const T*)p.W + (size_t)w_row[j] * p.ldw + (size_t)s * KC) + kc * 16);
+      rw[j] = w;
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int row = (tid >> 2) + 64 * j;
+      *(u32x4*)(&smem[buf][row * FWD_ROWB + kc * 16]) = ra[j];
+      *(u32x4*)(&smem[buf][(128 + row) * FWD_ROWB + kc * 16]) = rw[j];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; s++) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_step(s + 1);
+    frag_t a[4], b[4];
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      a[i] = *(const frag_t*)(&smem[buf][(wm * 64 + i * 16 + fr) * FWD_ROWB + fq * 16]);
+      b[i] = *(const frag_t*)(&smem[buf][(128 + wn * 64 + i * 16 + fr) * FWD_ROWB + fq * 16]);
+    }
+    mma_step(a, b, acc);
+    if (s + 1 < nsteps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D[row = (lane>>4)*4 + r][col = lane&15]
+  OutT* C = (OutT*)p.C;
+  const int fq = lane >> 4, fr = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int m = m0 + wm * 64 + i * 16 + fq * 4 + r;
+      if (m >= p.M) continue;
+      int seq = m / p.rm.T_out;
+      size_t orow = m;
+      if (p.permA > 0) {
+        int t = m - seq * p.permT;          // permT == T_out here
+        int b_ = seq / p.permA, a_ = seq - b_ * p.permA;
+        orow = ((size_t)b_ * p.permT + t) * p.permA + a_;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int n = n0 + wn * 64 + j * 16 + fr;
+        if (n >= p.Npad) continue;
+        float v = 0.f;
+        if (n < p.Nout) {
+          v = acc[i][j][r];
+          if (p.bias) v += p.bias[n];
+          if (p.rowbias) v += p.rowbias[(size_t)seq * p.ldrb + n];
+          if (p.act == 1) v = fmaxf(v, 0.f);
+          else if (p.act == 2) v = mish_f(v);
+        }
+        C[orow * p.ldc + n] = from_f32<OutT>(v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[o, tap*Cin + c] = sum_m dY[m, o] * X[src(m, tap), c]
+// ------------------------------------------------------------------------------------------------
+struct GemmWgradParams {
+  const void* dY;  int ldy;  int Ycols;   // Ycols: padded column count of dY (multiple of 32)
+  const void* X;   int ldx;
+  const void* X2;  int ldx2;
+  int Csplit;
+  int M, Cin, taps;
+  RowMap rm;
+  float* dW;       int ldw;               // [Nout, taps*Cin] fp32
+  int Nout;
+  int ctiles;                             // ceil(Cin / 128)
+  int steps_per_split, splits;            // reduction steps (KR rows each) per z-slice
+};
+
+template <typename T> struct WgradTraits;
+template <> struct WgradTraits<bf16_t> { static constexpr int KR = 32, ROWB = 288, CPR = 16, EPC = 8; };
+template <> struct WgradTraits<float>  { static constexpr int KR = 16, ROWB = 528, CPR = 32, EPC = 4; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(GemmWgradParams p) {
+  typedef WgradTraits<T> TR;
+  constexpr int KR = TR::KR, ROWB = TR::ROWB, CPR = TR::CPR, EPC = TR::EPC;
+  constexpr int TILEB = KR * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2 * TILEB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int n0 = blockIdx.x * 128;
+  const int tap = blockIdx.y / p.ctiles;
+  const int c0 = (blockIdx.y - tap * p.ctiles) * 128;
+  const int total_steps = (p.M + KR - 1) / KR;
+  const int s_begin = blockIdx.z * p.steps_per_split;
+  int s_end = s_begin + p.steps_per_split;
+  if (s_end > total_steps) s_end = total_steps;
+  if (s_begin >= s_end) return;   // uniform for the whole workgroup
+
+  // which source holds channels [c0, c0+128)?  (Csplit is a multiple of 128 or equals Cin)
+  const T* xsrc = (const T*)p.X;
+  int ldx = p.ldx, cx = c0, cmax = p.Csplit;
+  if (c0 >= p.Csplit) { xsrc = (const T*)p.X2; ldx = p.ldx2; cx = c0 - p.Csplit; cmax = p.Cin - p.Csplit; }
+
+  u32x4 ry[2], rx[2];
+  auto load_step = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int c = tid + 256 * j;
+      int row = c / CPR, cc = c - row * CPR;
+      int m = s * KR + row;
+      u32x4 vy = {0u, 0u, 0u, 0u}, vx = {0u, 0u, 0u, 0u};
+      if (m < p.M) {
+        int col = n0 + cc * EPC;
+        if (col < p.Ycols) vy = *(const u32x4*)((const T*)p.dY + (size_t)m * p.ldy + col);
+        int xc = cx + cc * EPC;
+        if (xc < cmax) {
+          int n = m / p.rm.T_out;
+          int r = map_row(n, m - n * p.rm.T_out, tap, p.rm);
+          if (r >= 0) vx = *(const u32x4*)(xsrc + (size_t)r * ldx + xc);
+        }
+      }
+      ry[j] = vy;
+      rx[j] = vx;
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int c = tid + 256 * j;
+      int row = c / CPR, cc = c - row * CPR;
+      *(u32x4*)(&smem[buf][row * ROWB + cc * 16]) = ry[j];
+      *(u32x4*)(&smem[buf][TILEB + row * ROWB + cc * 16]) = rx[j];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  load_step(s_begin);
+  store_step(0);
+  __syncthreads();
+  for (int s = s_begin; s < s_end; s++) {
+    const int buf = (s - s_begin) & 1;
+    if (s + 1 < s_end) load_step(s + 1);
+    const unsigned char* Ys = &smem[buf][0];
+    const unsigned char* Xs = &smem[buf][TILEB];
+    if constexpr (sizeof(T) == 2) {
+      // transposed LDS reads: lane (group fq, r = fr) supplies row 8*fq + (r>>2) (+4), cols 4*(r&3)..+3 and
+      // receives column r of those 4 rows -> 8 consecutive reduction rows for its own output row/col.
+      bf16x8 a[4], b[4];
+      const int trow = 8 * fq + (fr >> 2), tcol = 4 * (fr & 3);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        typedef s16x4 __attribute__((address_space(3))) * lds_p;
+        const unsigned char* pa = Ys + trow * ROWB + (wn * 64 + i * 16 + tcol) * 2;
+        const unsigned char* pb = Xs + trow * ROWB + (wc * 64 + i * 16 + tcol) * 2;
+        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(pa));
+        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(pa + 4 * ROWB));
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(pb));
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(pb + 4 * ROWB));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        a[i] = __builtin_bit_cast(bf16x8, av);
+        b[i] = __builtin_bit_cast(bf16x8, bv);
+      }
+      mma_step(a, b, acc);
+    } else {
+      // fp32: MFMA s consumes reduction rows {4*fq + s}; one ds_read_b32 per operand per MFMA.
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+          a[i][s4] = *(const float*)(Ys + (4 * fq + s4) * ROWB + (wn * 64 + i * 16 + fr) * 4);
+          b[i][s4] = *(const float*)(Xs + (4 * fq + s4) * ROWB + (wc * 64 + i * 16 + fr) * 4);
+        }
+      mma_step(a, b, acc);
+    }
+    if (s + 1 < s_end) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int n = n0 + wn * 64 + i * 16 + fq * 4 + r;
+      if (n >= p.Nout) continue;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int c = c0 + wc * 64 + j * 16 + fr;
+        if (c >= p.Cin) continue;
+        float* dst = p.dW + (size_t)n * p.ldw + (size_t)tap * p.Cin + c;
+        if (p.splits > 1) atomicAdd(dst, acc[i][j][r]);
+        else *dst = acc[i][j][r];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: parameter layout (fp32) <-> GEMM layout [O, taps, Ipad]
+// ------------------------------------------------------------------------------------------------
+// dst[(o*taps + tap)*dst_ld + dst_off + i] = src[o*so + i*si + tap*st]; pad columns are never touched (the
+// host allocates the packed buffer zero-filled once), so several parameters can be packed side by side.
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int O, int I, int taps, long so,
+                                   long si, long st, int dst_ld, int dst_off) {
+  long total = (long)O * taps * I;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = e % I;
+    long r = e / I;
+    int tap = r % taps;
+    long o = r / taps;
+    dst[(o * taps + tap) * dst_ld + dst_off + i] = from_f32<T>(src[o * so + i * si + tap * st]);
+  }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ grad, int O, int I, int Ipad,
+                                    int taps, long so, long si, long st) {
+  long total = (long)O * I * taps;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int tap = e % taps;
+    long r = e / taps;
+    int i = r % I;
+    long o = r / I;
+    grad[o * so + i * si + tap * st] = packed[(o * taps + tap) * Ipad + i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static int check_rowmap(int T_out, int T_in, int stride, int pad, int tr) {
+  return (T_out > 0 && T_in > 0 && stride > 0 && pad >= 0 && (tr == 0 || tr == 1)) ? 0 : -1;
+}
+
+extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, const void* X2, int ldx2, int Csplit,
+                               int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr,
+                               const void* W, int ldw, int Nout, int Npad, const float* bias, const float* rowbias,
+                               int ldrb, void* C, int ldc, int act, int permT, int permA, hipStream_t stream) {
+  const int KC = dtype == MADIFF_BF16 ? 32 : 16;
+  if (M <= 0 || Nout <= 0) return 0;
+  if (check_rowmap(T_out, T_in, stride, pad, tr) || Cin <= 0 || Cin % KC || taps <= 0 || Npad < Nout || ldc < Npad ||
+      ldw < taps * Cin || (ldw * (dtype == MADIFF_BF16 ? 2 : 4)) % 16 || ldx < 0 || M % T_out)
+    return -1;
+  if (X2 == nullptr) Csplit = Cin;
+  if (Csplit % KC || Csplit > Cin || ldx < Csplit || (X2 && ldx2 < Cin - Csplit)) return -1;
+  if ((ldx * (dtype == MADIFF_BF16 ? 2 : 4)) % 16 || (X2 && (ldx2 * (dtype == MADIFF_BF16 ? 2 : 4)) % 16)) return -1;
+  if (permA > 0 && (permT != T_out || (M / T_out) % permA)) return -1;
+  GemmFwdParams p;
+  p.X = X; p.ldx = ldx; p.X2 = X2; p.ldx2 = ldx2; p.Csplit = Csplit;
+  p.M = M; p.Cin = Cin; p.taps = taps;
+  p.rm = RowMap{T_out, T_in, stride, pad, tr};
+  p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Npad; p.bias = bias; p.rowbias = rowbias; p.ldrb = ldrb;
+  p.C = C; p.ldc = ldc; p.act = act; p.permT = permT; p.permA = permA;
+  dim3 grid((M + 127) / 128, (Npad + 127) / 128), block(256);
+  if (dtype == MADIFF_BF16) {
+    if (out_f32) hipLaunchKernelGGL((gemm_fwd_kernel<bf16_t, float>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((gemm_fwd_kernel<float, float>), grid, block, 0, stream, p);
+  }
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2,
+                                 int ldx2, int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride,
+                                 int pad, int tr, float* dW, int ldw, int Nout, hipStream_t stream) {
+  const int es = dtype == MADIFF_BF16 ? 2 : 4;
+  if (M <= 0 || Nout <= 0) return 0;
+  if (check_rowmap(T_out, T_in, stride, pad, tr) || Cin <= 0 || Cin % 32 || taps <= 0 || ldw < taps * Cin ||
+      Ycols % 32 || ldy < Ycols || (ldy * es) % 16 || (ldx * es) % 16 || M % T_out)
+    return -1;
+  if (X2 == nullptr) Csplit = Cin;
+  if (Csplit > Cin || ldx < Csplit || (X2 && (Csplit % 128 || ldx2 < Cin - Csplit || (ldx2 * es) % 16))) return -1;
+  GemmWgradParams p;
+  p.dY = dY; p.ldy = ldy; p.Ycols = Ycols; p.X = X; p.ldx = ldx; p.X2 = X2; p.ldx2 = ldx2; p.Csplit = Csplit;
+  p.M = M; p.Cin = Cin; p.taps = taps; p.rm = RowMap{T_out, T_in, stride, pad, tr};
+  p.dW = dW; p.ldw = ldw; p.Nout = Nout;
+  p.ctiles = (Cin + 127) / 128;
+  const int KR = dtype == MADIFF_BF16 ? 32 : 16;
+  int total_steps = (M + KR - 1) / KR;
+  int tiles = ((Nout + 127) / 128) * p.ctiles * taps;
+  int splits = (1024 + tiles - 1) / tiles;              // aim at ~1024 workgroups
+  if (splits > total_steps / 4) splits = total_steps / 4 > 0 ? total_steps / 4 : 1;
+  if (splits < 1) splits = 1;
+  p.steps_per_split = (total_steps + splits - 1) / splits;
+  p.splits = (total_steps + p.steps_per_split - 1) / p.steps_per_split;
+  if (p.splits > 1) {
+    hipError_t e = hipMemsetAsync(dW, 0, (size_t)Nout * ldw * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  dim3 grid((Nout + 127) / 128, p.ctiles * taps, p.splits), block(256);
+  if (dtype == MADIFF_BF16) hipLaunchKernelGGL((gemm_wgrad_kernel<bf16_t>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((gemm_wgrad_kernel<float>), grid, block, 0, stream, p);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_pack_weight(int dtype, const float* src, void* dst, int O, int I, int taps, long so, long si,
+                                  long st, int dst_ld, int dst_off, hipStream_t stream) {
+  if (O <= 0 || I <= 0 || taps <= 0 || dst_off < 0 || dst_ld < dst_off + I) return -1;
+  long total = (long)O * taps * I;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, O, I, taps, so, si, st, dst_ld, dst_off);
+  else
+    hipLaunchKernelGGL((pack_weight_kernel<float>), dim3(blocks), dim3(256), 0, stream, src, (float*)dst, O, I, taps, so, si, st, dst_ld, dst_off);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_unpack_wgrad(const float* packed, float* grad, int O, int I, int Ipad, int taps, long so, long si,
+                                   long st, hipStream_t stream) {
+  if (O <= 0 || I <= 0 || Ipad < I || taps <= 0) return -1;
+  long total = (long)O * I * taps;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, packed, grad, O, I, Ipad, taps, so, si, st);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}

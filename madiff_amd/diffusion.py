@@ -1,0 +1,344 @@
+"""GaussianDiffusion on the HIP kernels: same constructor, attributes, ``state_dict`` keys and call surface as
+/root/reference/diffuser/models/diffusion.py:13-499 (``loss(**batch)``, ``conditional_sample``, ``forward``,
+``set_ddim_scheduler``, ``inv_model``); ``p_sample_loop`` is an alias of ``conditional_sample``.
+
+Differences that are additions, not changes of behaviour:
+* every random draw of the reference may be supplied explicitly (``t``, ``noise``, ``dropout_mask`` to
+  ``loss``; ``x_init``/``step_noise`` to ``conditional_sample``) so results can be compared bit-for-bit in
+  draw order with the reference; without them torch's RNG is used in the reference's draw order;
+* the K-step loop can be captured into ONE hipGraph step that is replayed K times with a device-side step
+  counter (``use_graph=True``, the default on a GPU): inpaint -> one 2B-batch guided forward -> fused
+  posterior step;
+* the classifier-free-guidance pair runs as one 2B batch.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .modules import rows_to_cl
+from .ops import LINEAR, MaskedStateLoss, conv_gemm, pad32
+from .schedulers import DDIMScheduler, DDPMScheduler
+
+
+class Encoder(object):
+    def __call__(self, data):
+        raise NotImplementedError
+
+
+class IdentityEncoder(Encoder):
+    """diffuser/utils/data_encoder.py:6-8."""
+
+    def __call__(self, data):
+        return data
+
+
+class InvDynMLP(nn.Sequential):
+    """Linear-ReLU-Linear-ReLU-Linear[-Softmax] inverse-dynamics head (diffusion.py:100-137) whose three
+    contractions run on the MFMA GEMM kernel (ReLU fused in the epilogue).  Children keep the reference's
+    nn.Sequential indices 0, 2, 4 so checkpoints load unchanged; callable on [..., in_dim] like the original."""
+
+    def __init__(self, in_dim, hidden_dim, out_dim, softmax=False):
+        mods = [nn.Linear(in_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, hidden_dim), nn.ReLU(),
+                nn.Linear(hidden_dim, out_dim)]
+        if softmax:
+            mods.append(nn.Softmax(dim=-1))
+        else:
+            mods.append(nn.Identity())
+        super().__init__(*mods)
+        self.out_dim = out_dim
+        self.softmax = softmax
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        h = rows_to_cl(x.reshape(-1, x.shape[-1]).to(torch.float32))
+        h = conv_gemm(h, [self[0].weight], [self[0].bias], LINEAR, 1, act=1)
+        h = conv_gemm(h, [self[2].weight], [self[2].bias], LINEAR, 1, act=1)
+        h = conv_gemm(h, [self[4].weight], [self[4].bias], LINEAR, 1, perm="f32")[:, : self.out_dim]
+        if self.softmax:
+            h = torch.softmax(h, dim=-1)
+        return h.reshape(*lead, self.out_dim)
+
+
+class WeightedStateL2(nn.Module):
+    """helpers.py:238-251,292-294 (the ``state_l2`` loss): holds the ``weights`` buffer [T, A, F]."""
+
+    def __init__(self, weights):
+        super().__init__()
+        self.register_buffer("weights", weights)
+
+    def forward(self, pred, targ):
+        loss = F.mse_loss(pred, targ, reduction="none") * self.weights
+        return loss, {"a0_loss": loss.mean()}
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, model, n_agents: int, horizon: int, history_horizon: int, observation_dim: int,
+                 action_dim: int, use_inv_dyn: bool = True, discrete_action: bool = False, num_actions: int = 0,
+                 n_timesteps: int = 1000, clip_denoised: bool = False, predict_epsilon: bool = True,
+                 action_weight: float = 1.0, hidden_dim: int = 256, loss_discount: float = 1.0,
+                 loss_weights: np.ndarray = None, state_loss_weight: float = None,
+                 opponent_loss_weight: float = None, returns_condition: bool = False,
+                 condition_guidance_w: float = 1.2, returns_loss_guided: bool = False, loss_guidence_w: float = 0.1,
+                 value_diffusion_model: nn.Module = None, train_only_inv: bool = False, share_inv: bool = True,
+                 joint_inv: bool = False, data_encoder: Encoder = IdentityEncoder(), **kwargs):
+        assert action_dim > 0
+        assert not returns_condition or not returns_loss_guided, \
+            "Can't do both returns conditioning and returns loss guidence"
+        if not use_inv_dyn or not predict_epsilon or returns_loss_guided or value_diffusion_model is not None:
+            raise NotImplementedError("only the configuration every exp_spec uses is on the hot path: "
+                                      "use_inv_dyn=True, predict_epsilon=True, no value guidance (SURVEY.md section 2)")
+        super().__init__()
+        self.n_agents = n_agents
+        self.horizon = horizon
+        self.history_horizon = history_horizon
+        self.observation_dim = observation_dim
+        self.action_dim = action_dim
+        self.state_loss_weight = state_loss_weight
+        self.opponent_loss_weight = opponent_loss_weight
+        self.discrete_action = discrete_action
+        self.num_actions = num_actions
+        self.transition_dim = observation_dim + action_dim
+        self.model = model
+        self.use_inv_dyn = use_inv_dyn
+        self.train_only_inv = train_only_inv
+        self.share_inv = share_inv
+        self.joint_inv = joint_inv
+        self.data_encoder = data_encoder
+        self.inv_model = self._build_inv_model(hidden_dim, output_dim=action_dim if not discrete_action else num_actions)
+        self.returns_condition = returns_condition
+        self.condition_guidance_w = condition_guidance_w
+        self.returns_loss_guided = returns_loss_guided
+        self.loss_guidence_w = loss_guidence_w
+        self.value_diffusion_model = None
+        self.n_timesteps = int(n_timesteps)
+        self.clip_denoised = clip_denoised
+        self.predict_epsilon = predict_epsilon
+        self.noise_scheduler = DDPMScheduler(num_train_timesteps=self.n_timesteps, clip_sample=True,
+                                             prediction_type="epsilon", beta_schedule="squaredcos_cap_v2")
+        self.use_ddim_sample = False
+        self.loss_fn = WeightedStateL2(self.get_loss_weights(loss_discount, action_weight))
+        self._tables: dict = {}
+        self._graphs: dict = {}
+
+    # ------------------------------------------------------------------ construction helpers
+    def _build_inv_model(self, hidden_dim: int, output_dim: int):
+        if self.joint_inv:
+            return InvDynMLP(self.n_agents * 2 * self.observation_dim, hidden_dim, self.n_agents * output_dim)
+        if self.share_inv:
+            return InvDynMLP(2 * self.observation_dim, hidden_dim, output_dim)
+        return nn.ModuleList([InvDynMLP(2 * self.observation_dim, hidden_dim, output_dim, softmax=self.discrete_action)
+                              for _ in range(self.n_agents)])
+
+    def set_ddim_scheduler(self, n_ddim_steps: int = 15):
+        self.ddim_noise_scheduler = DDIMScheduler(num_train_timesteps=self.n_timesteps, clip_sample=True,
+                                                  prediction_type="epsilon", beta_schedule="squaredcos_cap_v2")
+        self.ddim_noise_scheduler.set_timesteps(n_ddim_steps)
+        self.use_ddim_sample = True
+        self._graphs.clear()
+
+    def get_loss_weights(self, discount: float, action_weight: Optional[float] = None):
+        """diffusion.py:149-172 with use_inv_dyn=True: discount**t over the prediction horizon, zeros over the
+        history, broadcast over agents and observation dims -> [T, A, F]."""
+        dim_weights = torch.ones(self.observation_dim, dtype=torch.float32)
+        discounts = discount ** torch.arange(self.horizon, dtype=torch.float)
+        discounts = discounts / discounts.mean()
+        discounts = torch.cat([torch.zeros(self.history_horizon), discounts])
+        w = torch.einsum("h,t->ht", discounts, dim_weights)
+        return w.unsqueeze(1).expand(-1, self.n_agents, -1).clone()
+
+    def _sched_tables(self, sched, device):
+        """Device-resident tables of a scheduler: sqrt(abar), sqrt(1-abar), posterior coefficient rows, timesteps."""
+        key = (id(sched), str(device), tuple(sched.timesteps.tolist()))
+        tb = self._tables.get(key)
+        if tb is None:
+            ac = sched.alphas_cumprod
+            tb = {"sqrt_ac": (ac ** 0.5).to(device).contiguous(), "sqrt_1mac": ((1 - ac) ** 0.5).to(device).contiguous(),
+                  "coef": sched.coef_table().to(device).contiguous(),
+                  "timesteps": sched.timesteps.to(device=device, dtype=torch.int64).contiguous()}
+            self._tables = {key: tb}
+        return tb
+
+    # ------------------------------------------------------------------ sampling
+    def get_model_output(self, x, t, returns=None, env_ts=None, attention_masks=None, states=None):
+        """Guided epsilon (diffusion.py:176-212); the blend itself is fused into the posterior kernel during
+        sampling, this entry point returns the blended tensor for callers that want it."""
+        if self.returns_condition:
+            ec, eu = self.model.forward_guided_pair(ops.pack_traj(x.contiguous(), pad32(x.shape[-1])), x.shape[0],
+                                                    x.shape[1], t, returns, env_ts)
+            return eu + self.condition_guidance_w * (ec - eu)
+        return self.model(x, t, env_timestep=env_ts, attention_masks=attention_masks)
+
+    def _denoise_step(self, st, returns, env_ts, bsz, t_len):
+        """One loop iteration on persistent buffers (graph-capturable): eps from x (already inpainted), then the
+        fused posterior step + inpainting writes the next x in place."""
+        x = st["x"]
+        lib = ops.lib
+        lib.call("madiff_sampler_fill_time", st["state"].data_ptr(), st["tsteps"].data_ptr(), st["ts"].data_ptr(), bsz,
+                 ops._stream())
+        xcl = ops.pack_traj(x, pad32(x.shape[-1]))
+        if self.returns_condition:
+            ec, eu = self.model.forward_guided_pair(xcl, bsz, t_len, st["ts"], returns, env_ts)
+        else:
+            temb = self.model.net.embed(st["ts"], None, self.n_agents, False, False, None, env_ts)
+            ec, eu = self.model.forward_cl(xcl, bsz, t_len, temb), None
+        z = st["z"]
+        ops.posterior_step(x, ec.contiguous(), None if eu is None else eu.contiguous(), self.condition_guidance_w, z,
+                           st["cond_x"], st["mask"], st["coef"], x, step_ptr=st["state"])
+        lib.call("madiff_sampler_advance", st["state"].data_ptr(), ops._stream())
+
+    @torch.no_grad()
+    def conditional_sample(self, cond: Dict[str, torch.Tensor], returns: Optional[torch.Tensor] = None,
+                           env_ts: Optional[torch.Tensor] = None, horizon: int = None,
+                           attention_masks: Optional[torch.Tensor] = None, verbose: bool = True,
+                           return_diffusion: bool = False, x_init: Optional[torch.Tensor] = None,
+                           step_noise: Optional[torch.Tensor] = None, use_graph: Optional[bool] = None):
+        """diffusion.py:214-275.  ``x_init`` = the tempered initial draw (0.5*randn); ``step_noise`` [n_steps, B,T,A,F]
+        = the N(0,1) draws of the scheduler steps (row i is consumed by loop iteration i)."""
+        batch_size = cond["x"].shape[0]
+        t_len = horizon or self.horizon + self.history_horizon
+        shape = (batch_size, t_len, self.n_agents, self.observation_dim)
+        device = cond["x"].device
+        sched = self.ddim_noise_scheduler if self.use_ddim_sample else self.noise_scheduler
+        tb = self._sched_tables(sched, device)
+        n_steps = tb["timesteps"].shape[0]
+        if not isinstance(self.data_encoder, IdentityEncoder):
+            raise NotImplementedError("non-identity data encoders are outside the hot path (SURVEY.md 8f F4)")
+        if use_graph is None:
+            use_graph = not return_diffusion
+
+        x = (0.5 * torch.randn(shape, device=device)) if x_init is None else x_init.to(device, torch.float32).clone()
+        needs_z = not self.use_ddim_sample
+        cond_x = cond["x"].to(device, torch.float32).contiguous()
+        mask = cond["masks"].to(device=device, dtype=torch.uint8).contiguous()
+        st = {"x": x.contiguous(), "cond_x": cond_x, "mask": mask, "coef": tb["coef"], "tsteps": tb["timesteps"],
+              "state": torch.zeros(1, dtype=torch.int32, device=device),
+              "ts": torch.zeros(batch_size, dtype=torch.int64, device=device),
+              "z": torch.empty(shape, dtype=torch.float32, device=device) if needs_z else None}
+        ops.inpaint_(st["x"], cond_x, mask)                       # step 1 of the first iteration (diffusion.py:251)
+        chain = [st["x"].clone()] if return_diffusion else None
+        if returns is not None:
+            returns = returns.to(device, torch.float32).contiguous()
+
+        def draw(i):
+            if not needs_z:
+                return
+            if step_noise is not None:
+                if i < step_noise.shape[0]:
+                    st["z"].copy_(step_noise[i])
+            else:
+                st["z"].normal_()
+
+        graph = None
+        for i in range(n_steps):
+            draw(i)
+            if graph is not None:
+                graph.replay()
+            elif use_graph and i == 1 and n_steps > 2:
+                # iteration 0 ran eagerly (it filled the weight-pack cache and warmed the allocator); capture
+                # iteration 1 and replay it for the rest: the step index lives on the device, so one captured
+                # step serves every iteration.  Capture does not execute, hence the replay right after.
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._denoise_step(st, returns, env_ts, batch_size, t_len)
+                graph.replay()
+            else:
+                self._denoise_step(st, returns, env_ts, batch_size, t_len)
+            if return_diffusion:
+                chain.append(st["x"].clone())
+        x = st["x"]        # the posterior kernel already enforced the final conditioning (diffusion.py:268)
+        if return_diffusion:
+            return x, torch.stack(chain, dim=1)
+        return x
+
+    p_sample_loop = conditional_sample
+
+    # ------------------------------------------------------------------ training
+    def p_losses(self, x_start, cond, t, loss_masks, attention_masks=None, returns=None, env_ts=None, states=None,
+                 noise=None, dropout_mask=None):
+        """diffusion.py:279-337.  add_noise + inpainting + layout change are one kernel; the masked weighted MSE
+        and its gradient are one kernel each."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        device = x_start.device
+        tb = self._sched_tables(self.noise_scheduler, device)
+        B, T, A, Fd = x_start.shape
+        mask = cond["masks"].to(device=device, dtype=torch.uint8).contiguous()
+        xcl = ops.pack_traj(x_start.to(torch.float32), pad32(Fd), noise=noise.contiguous(), t=t.contiguous(),
+                            sqrt_ac=tb["sqrt_ac"], sqrt_1mac=tb["sqrt_1mac"],
+                            cond=cond["x"].to(device, torch.float32).contiguous(), mask=mask)
+        temb = self.model.net.embed(t, returns if self.model.returns_condition else None, A, True, False,
+                                    dropout_mask, env_ts)
+        epsilon = self.model.forward_cl(xcl, B, T, temb)
+        assert noise.shape == epsilon.shape
+        m32 = loss_masks.to(device=device, dtype=torch.float32).reshape(B, T, A).contiguous()
+        loss, a0 = MaskedStateLoss.apply(epsilon, noise, self.loss_fn.weights.contiguous(), m32)
+        if loss_masks.dtype != torch.float64:
+            loss = loss.to(loss_masks.dtype)
+        return loss, {"a0_loss": a0}
+
+    def compute_inv_loss(self, x, loss_masks, legal_actions=None):
+        """diffusion.py:369-436.  The MLP contractions run on the HIP GEMM; the tiny per-row loss algebra on the
+        logits stays in torch."""
+        info = {}
+        ad, od = self.action_dim, self.observation_dim
+        x_comb_t = torch.cat([x[:, :-1, :, ad:], x[:, 1:, :, ad:]], dim=-1).reshape(-1, x.shape[2], 2 * od)
+        a_t = x[:, :-1, :, :ad].reshape(-1, x.shape[2], ad)
+        masks_t = loss_masks[:, 1:].reshape(-1, loss_masks.shape[2])
+        if legal_actions is not None:
+            legal_actions_t = legal_actions[:, :-1].reshape(-1, *legal_actions.shape[2:])
+        if self.joint_inv or self.share_inv:
+            if self.joint_inv:
+                pred_a_t = self.inv_model(x_comb_t.reshape(x_comb_t.shape[0], -1)).reshape(
+                    x_comb_t.shape[0], x_comb_t.shape[1], -1)
+            else:
+                pred_a_t = self.inv_model(x_comb_t)
+            if legal_actions is not None:
+                pred_a_t = torch.where(legal_actions_t == 0, torch.full_like(pred_a_t, -1e10), pred_a_t)
+            if self.discrete_action:
+                inv_loss = (F.cross_entropy(pred_a_t.reshape(-1, pred_a_t.shape[-1]), a_t.reshape(-1).long(),
+                                            reduction="none") * masks_t.reshape(-1)).mean() / masks_t.mean()
+                inv_acc = ((pred_a_t.argmax(dim=-1, keepdim=True) == a_t).to(dtype=float).squeeze(-1)
+                           * masks_t).mean() / masks_t.mean()
+                info["inv_acc"] = inv_acc
+            else:
+                inv_loss = (F.mse_loss(pred_a_t, a_t, reduction="none") * masks_t.unsqueeze(-1)).mean() / masks_t.mean()
+        else:
+            inv_loss = 0.0
+            for i in range(self.n_agents):
+                pred_a_t = self.inv_model[i](x_comb_t[:, i])
+                if self.discrete_action:
+                    inv_loss += (F.cross_entropy(pred_a_t, a_t[:, i].reshape(-1).long(), reduction="none")
+                                 * masks_t[:, i]).mean() / masks_t[:, i].mean()
+                else:
+                    inv_loss += (F.mse_loss(pred_a_t, a_t[:, i]) * masks_t[:, i].unsqueeze(-1)).mean() \
+                        / masks_t[:, i].mean()
+        return inv_loss, info
+
+    def loss(self, x, cond, loss_masks, attention_masks=None, returns=None, env_ts=None, states=None,
+             legal_actions=None, t=None, noise=None, dropout_mask=None):
+        """diffusion.py:438-496; called as ``loss(**batch)``."""
+        if self.train_only_inv:
+            info = {}
+        else:
+            batch_size = len(x)
+            if t is None:
+                t = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (batch_size,),
+                                  device=x.device).long()
+            diffuse_loss, info = self.p_losses(x[..., self.action_dim:], cond, t, loss_masks, attention_masks, returns,
+                                               env_ts, states, noise=noise, dropout_mask=dropout_mask)
+        inv_loss, inv_info = self.compute_inv_loss(x, loss_masks, legal_actions)
+        info = {**info, **inv_info}
+        info["inv_loss"] = inv_loss
+        if self.train_only_inv:
+            return inv_loss, info
+        return (1 / 2) * (diffuse_loss + inv_loss), info
+
+    def forward(self, cond, *args, **kwargs):
+        return self.conditional_sample(cond=cond, *args, **kwargs)

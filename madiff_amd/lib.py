@@ -1,0 +1,80 @@
+"""ctypes binding of libmadiff_hip.so (the C ABI declared in include/madiff_hip.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load, importing this
+module raises, and every op raises RuntimeError on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads torch's bundled libamdhip64 first so this library binds to the SAME HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmadiff_hip.so")
+
+F32, BF16 = 0, 1
+
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+_SIGS = {
+    "madiff_gemm_fwd": [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i,
+                        _vp, _i, _i, _i, _i, _vp],
+    "madiff_gemm_wgrad": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    "madiff_pack_weight": [_i, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
+    "madiff_unpack_wgrad": [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _vp],
+    "madiff_gn_mish_fwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _i, _vp],
+    "madiff_gn_mish_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "madiff_attn_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "madiff_attn_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "madiff_pack_input": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "madiff_unpack_output": [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "madiff_posterior_step": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp],
+    "madiff_inpaint": [_vp, _vp, _vp, _l, _vp],
+    "madiff_sampler_fill_time": [_vp, _vp, _vp, _i, _vp],
+    "madiff_sampler_advance": [_vp, _vp],
+    "madiff_mse_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "madiff_mse_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "madiff_sinusoid": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "madiff_act_fwd": [_i, _i, _vp, _vp, _l, _vp],
+    "madiff_act_bwd": [_i, _i, _vp, _vp, _vp, _l, _vp],
+    "madiff_colsum": [_i, _vp, _i, _vp, _l, _i, _vp],
+    "madiff_seqsum": [_i, _vp, _i, _vp, _i, _l, _i, _i, _vp],
+    "madiff_adam_ema": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp],
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C madiff_amd/csrc` (or __graft_entry__.build()). "
+        "madiff_amd has no CPU or PyTorch fallback.")
+
+_lib = C.CDLL(LIB_PATH)
+for _name, _args in _SIGS.items():
+    _fn = getattr(_lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = _i
+_lib.madiff_version.restype = _i
+_lib.madiff_arch.restype = C.c_char_p
+
+
+def version() -> int:
+    return _lib.madiff_version()
+
+
+def arch() -> str:
+    return _lib.madiff_arch().decode()
+
+
+def call(name: str, *args) -> None:
+    """Call a C-ABI entry point; raise RuntimeError on a non-zero status."""
+    rc = getattr(_lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with status {rc}" + (" (invalid argument)" if rc == -1 else " (hipError_t)"))
+
+
+def exported(name: str) -> bool:
+    try:
+        getattr(_lib, name)
+        return True
+    except AttributeError:
+        return False

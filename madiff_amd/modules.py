@@ -1,0 +1,409 @@
+"""Host-side mirror of the reference's ``diffuser.models`` denoiser surface, executing on the HIP kernels.
+
+Same class names, constructor arguments, attributes, ``state_dict`` keys and parameter shapes as
+/root/reference/diffuser/models/{helpers,temporal,ma_temporal}.py (cited per class), so reference checkpoints
+load unchanged and ``utils.Config`` / ``copy.deepcopy`` / ``Adam(model.parameters())`` keep working.  The
+nn.Conv1d / nn.Linear / nn.GroupNorm children are parameter holders only: their own ``forward`` is never used
+on the hot path; every contraction, normalisation and the attention core run through ``madiff_amd.ops``.
+
+Internally activations are channels-last ("cl") matrices [(sequence, time), pad32(channels)].
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.distributions import Bernoulli
+
+from . import ops
+from .ops import CONV1, CONV5, DOWN, LINEAR, UP, AttnCore, GNMish, PackTraj, conv_gemm, mish, pad32
+
+
+# ------------------------------------------------------------------------------------------------
+# layout glue for the module-level ([N, C, T]) interfaces
+# ------------------------------------------------------------------------------------------------
+def to_cl(x: torch.Tensor) -> torch.Tensor:
+    """[N, C, T] -> cl [N*T, pad32(C)] (differentiable torch glue; only used by the per-module entry points)."""
+    n, c, t = x.shape
+    y = x.permute(0, 2, 1).reshape(n * t, c)
+    if pad32(c) != c:
+        y = torch.nn.functional.pad(y, (0, pad32(c) - c))
+    return y.to(ops.act_dtype()).contiguous()
+
+
+def from_cl(y: torch.Tensor, n: int, t: int, c: int) -> torch.Tensor:
+    return y[:, :c].reshape(n, t, c).permute(0, 2, 1).float()
+
+
+def rows_to_cl(x: torch.Tensor) -> torch.Tensor:
+    """[rows, C] fp32 -> cl [rows, pad32(C)]."""
+    c = x.shape[-1]
+    if pad32(c) != c:
+        x = torch.nn.functional.pad(x, (0, pad32(c) - c))
+    return x.to(ops.act_dtype()).contiguous()
+
+
+class _Tag(nn.Identity):
+    """Parameter-free placeholder keeping the reference's nn.Sequential indices (Rearrange / Mish slots)."""
+
+
+# ------------------------------------------------------------------------------------------------
+# leaves (helpers.py)
+# ------------------------------------------------------------------------------------------------
+class SinusoidalPosEmb(nn.Module):
+    """helpers.py:17-29."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def freq(self, device) -> torch.Tensor:
+        """exp(-j ln(1e4)/(half-1)) evaluated on the host in fp32 like the reference, cached per device (no H2D copy
+        inside a captured graph)."""
+        cache = self.__dict__.setdefault("_freq_cache", {})
+        key = str(device)
+        if key not in cache:
+            half = self.dim // 2
+            cache[key] = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(device)
+        return cache[key]
+
+    def __deepcopy__(self, memo):
+        return SinusoidalPosEmb(self.dim)
+
+    def forward(self, x):
+        shape = x.shape
+        ts = x.reshape(-1).to(torch.int64).contiguous()
+        out = ops.sinusoid(ts, self.freq(x.device), 1)
+        return out[:, : self.dim].float().reshape(*shape, self.dim)
+
+
+class Downsample1d(nn.Module):
+    """helpers.py:32-38: Conv1d(dim, dim, 3, stride 2, pad 1)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.conv = nn.Conv1d(dim, dim, 3, 2, 1)
+
+    def forward_cl(self, x, t):
+        return conv_gemm(x, [self.conv.weight], [self.conv.bias], DOWN, t), DOWN.out_len(t)
+
+    def forward(self, x):
+        n, c, t = x.shape
+        y, t2 = self.forward_cl(to_cl(x), t)
+        return from_cl(y, n, t2, c)
+
+
+class Upsample1d(nn.Module):
+    """helpers.py:41-47: ConvTranspose1d(dim, dim, 4, stride 2, pad 1)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.conv = nn.ConvTranspose1d(dim, dim, 4, 2, 1)
+
+    def forward_cl(self, x, t):
+        return conv_gemm(x, [self.conv.weight], [self.conv.bias], UP, t), UP.out_len(t)
+
+    def forward(self, x):
+        n, c, t = x.shape
+        y, t2 = self.forward_cl(to_cl(x), t)
+        return from_cl(y, n, t2, c)
+
+
+class Conv1dBlock(nn.Module):
+    """helpers.py:50-74: Conv1d -> GroupNorm(8) -> Mish.  keys: block.0.{weight,bias}, block.2.{weight,bias}."""
+
+    def __init__(self, inp_channels, out_channels, kernel_size, mish=True, n_groups=8):
+        super().__init__()
+        if not mish:
+            raise NotImplementedError("the reference always builds Mish blocks (temporal.py:225)")
+        self.block = nn.Sequential(
+            nn.Conv1d(inp_channels, out_channels, kernel_size, padding=kernel_size // 2),
+            _Tag(), nn.GroupNorm(n_groups, out_channels), _Tag(), _Tag())
+        self.out_channels = out_channels
+        self.n_groups = n_groups
+        self.spec = CONV5 if kernel_size == 5 else ops.ConvSpec("conv", kernel_size, 1, kernel_size // 2, 0)
+
+    def forward_cl(self, x, t, x2=None, rowbias=None, res=None):
+        conv, gn = self.block[0], self.block[2]
+        y = conv_gemm(x, [conv.weight], [conv.bias], self.spec, t, x2=x2)
+        return GNMish.apply(y, gn.weight, gn.bias, rowbias, res, y.shape[0] // t, t, self.out_channels, self.n_groups)
+
+    def forward(self, x):
+        n, _, t = x.shape
+        return from_cl(self.forward_cl(to_cl(x), t), n, t, self.out_channels)
+
+
+# ------------------------------------------------------------------------------------------------
+# temporal.py
+# ------------------------------------------------------------------------------------------------
+class ResidualTemporalBlock(nn.Module):
+    """temporal.py:161-200.  keys: blocks.{0,1}.block.*, time_mlp.1.*, residual_conv.*"""
+
+    def __init__(self, inp_channels, out_channels, embed_dim, kernel_size=5, mish=True):
+        super().__init__()
+        self.blocks = nn.ModuleList([Conv1dBlock(inp_channels, out_channels, kernel_size, mish),
+                                     Conv1dBlock(out_channels, out_channels, kernel_size, mish)])
+        self.time_mlp = nn.Sequential(_Tag(), nn.Linear(embed_dim, out_channels), _Tag())
+        self.residual_conv = nn.Conv1d(inp_channels, out_channels, 1) if inp_channels != out_channels else nn.Identity()
+        self.out_channels = out_channels
+
+    def forward_cl(self, x, t, temb_proj, x2=None):
+        """x cl [N*t, Cin]; temb_proj fp32 [N, >=Cout] = Linear(Mish(t_emb)) (computed by the fused time GEMM)."""
+        h = self.blocks[0].forward_cl(x, t, x2=x2, rowbias=temb_proj)
+        if isinstance(self.residual_conv, nn.Conv1d):
+            res = conv_gemm(x, [self.residual_conv.weight], [self.residual_conv.bias], CONV1, t, x2=x2)
+        else:
+            assert x2 is None
+            res = x
+        return self.blocks[1].forward_cl(h, t, res=res)
+
+    def forward(self, x, t):
+        n, _, tl = x.shape
+        lin = self.time_mlp[1]
+        proj = conv_gemm(mish(rows_to_cl(t)), [lin.weight], [lin.bias], LINEAR, 1, perm="f32")
+        return from_cl(self.forward_cl(to_cl(x), tl, proj), n, tl, self.out_channels)
+
+
+class TemporalSelfAttention(nn.Module):
+    """temporal.py:57-124: cross-agent attention with timestep-conditioned Q/K/V."""
+
+    def __init__(self, n_channels, qk_n_channels, v_n_channels, embed_dim, nheads=4, residual=False):
+        super().__init__()
+        self.nheads = nheads
+        self.query_layer = nn.Conv1d(n_channels, qk_n_channels * nheads, kernel_size=1)
+        self.key_layer = nn.Conv1d(n_channels, qk_n_channels * nheads, kernel_size=1)
+        self.value_layer = nn.Conv1d(n_channels, v_n_channels * nheads, kernel_size=1)
+        self.query_time_mlp = nn.Sequential(_Tag(), nn.Linear(embed_dim, qk_n_channels * nheads), _Tag())
+        self.key_time_mlp = nn.Sequential(_Tag(), nn.Linear(embed_dim, qk_n_channels * nheads), _Tag())
+        self.value_time_mlp = nn.Sequential(_Tag(), nn.Linear(embed_dim, v_n_channels * nheads), _Tag())
+        self.residual = residual
+        if residual:
+            self.gamma = nn.Parameter(torch.zeros([1]))
+        self.n_channels = n_channels
+        self.cq = qk_n_channels * nheads
+        self.cv = v_n_channels * nheads
+        if self.cv != n_channels:
+            raise NotImplementedError("value width must equal the channel count (out.reshape(x.shape), temporal.py:121)")
+
+    def time_layers(self) -> List[nn.Linear]:
+        return [self.query_time_mlp[1], self.key_time_mlp[1], self.value_time_mlp[1]]
+
+    def forward_cl(self, x, bsz, n_agents, t, time_proj):
+        """x cl [(b a) t, C]; time_proj fp32 [B*A, >= 2cq + C] = [q | k | v] time-MLP outputs."""
+        qkv = conv_gemm(x, [self.query_layer.weight, self.key_layer.weight, self.value_layer.weight],
+                        [self.query_layer.bias, self.key_layer.bias, self.value_layer.bias], CONV1, t,
+                        rowbias=time_proj)
+        return AttnCore.apply(qkv, x, self.gamma if self.residual else None, bsz, n_agents, t, self.nheads, self.cq,
+                              self.n_channels, self.residual)
+
+    def forward(self, x, time):
+        b, a, c, t = x.shape
+        tl = self.time_layers()
+        proj = conv_gemm(mish(rows_to_cl(time.reshape(b * a, -1))), [l.weight for l in tl], [l.bias for l in tl],
+                         LINEAR, 1, perm="f32")
+        y = self.forward_cl(to_cl(x.reshape(b * a, c, t)), b, a, t, proj)
+        return from_cl(y, b * a, t, c).reshape(b, a, c, t)
+
+
+class TemporalUnet(nn.Module):
+    """temporal.py:203-346 (constructor = parameter layout).  Its forward is only used for a single agent
+    group; SharedConvAttentionDeconv drives the blocks itself."""
+
+    agent_share_parameters = True
+
+    def __init__(self, horizon, transition_dim, history_horizon=0, dim=128, dim_mults=(1, 2, 4, 8),
+                 returns_condition=False, env_ts_condition=False, condition_dropout=0.1, kernel_size=5,
+                 max_path_length=100):
+        super().__init__()
+        dims = [transition_dim, *map(lambda m: dim * m, dim_mults)]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        self.in_out = in_out
+        self.time_dim = dim
+        self.returns_dim = dim
+        self.transition_dim = transition_dim
+        self.time_mlp = nn.Sequential(SinusoidalPosEmb(dim), nn.Linear(dim, dim * 4), _Tag(), nn.Linear(dim * 4, dim))
+        embed_dim = dim
+        self.returns_condition = returns_condition
+        self.env_ts_condition = env_ts_condition
+        self.condition_dropout = condition_dropout
+        self.history_horizon = history_horizon
+        if returns_condition:
+            self.returns_mlp = nn.Sequential(nn.Linear(1, dim), _Tag(), nn.Linear(dim, dim * 4), _Tag(),
+                                             nn.Linear(dim * 4, dim))
+            self.mask_dist = Bernoulli(probs=1 - self.condition_dropout)
+            embed_dim += dim
+        if env_ts_condition:
+            self.env_ts_mlp = nn.Sequential(nn.Embedding(max_path_length + 1, dim), nn.Linear(dim, dim * 4), _Tag(),
+                                            nn.Linear(dim * 4, dim))
+            embed_dim += dim
+        self.embed_dim = embed_dim
+
+        self.downs = nn.ModuleList([])
+        self.ups = nn.ModuleList([])
+        n_res = len(in_out)
+        for ind, (d_in, d_out) in enumerate(in_out):
+            is_last = ind >= (n_res - 1)
+            self.downs.append(nn.ModuleList([
+                ResidualTemporalBlock(d_in, d_out, embed_dim=embed_dim, kernel_size=kernel_size),
+                ResidualTemporalBlock(d_out, d_out, embed_dim=embed_dim, kernel_size=kernel_size),
+                Downsample1d(d_out) if not is_last else nn.Identity()]))
+        mid = dims[-1]
+        self.mid_block1 = ResidualTemporalBlock(mid, mid, embed_dim=embed_dim, kernel_size=kernel_size)
+        self.mid_block2 = ResidualTemporalBlock(mid, mid, embed_dim=embed_dim, kernel_size=kernel_size)
+        for ind, (d_in, d_out) in enumerate(reversed(in_out[1:])):
+            is_last = ind >= (n_res - 1)
+            self.ups.append(nn.ModuleList([
+                ResidualTemporalBlock(d_out * 2, d_in, embed_dim=embed_dim, kernel_size=kernel_size),
+                ResidualTemporalBlock(d_in, d_in, embed_dim=embed_dim, kernel_size=kernel_size),
+                Upsample1d(d_in) if not is_last else nn.Identity()]))
+        self.final_conv = nn.Sequential(Conv1dBlock(dim, dim, kernel_size=kernel_size), nn.Conv1d(dim, transition_dim, 1))
+
+    # -- embedding MLPs (ma_temporal.py:341-362 / temporal.py:365-384) ----------------------------------
+    def embed(self, time, returns, n_agents, use_dropout, force_dropout, dropout_mask=None, env_timestep=None):
+        """-> cl [B*A, pad32(embed_dim)] = cat(time_mlp(t), returns_mlp(r) * mask [, env_ts_mlp])."""
+        dim = self.time_dim
+        bsz = time.shape[0]
+        dev = time.device
+        e = ops.sinusoid(time.to(torch.int64).contiguous(), self.time_mlp[0].freq(dev), n_agents)
+        l1, l3 = self.time_mlp[1], self.time_mlp[3]
+        e = conv_gemm(mish(conv_gemm(e, [l1.weight], [l1.bias], LINEAR, 1)), [l3.weight], [l3.bias], LINEAR, 1)
+        parts = [e[:, :dim]]
+        if self.returns_condition:
+            assert returns is not None
+            r = returns.to(torch.float32).permute(0, 2, 1).reshape(bsz * n_agents, -1)   # "b t a -> b a t", t == 1
+            m0, m2, m4 = self.returns_mlp[0], self.returns_mlp[2], self.returns_mlp[4]
+            r = conv_gemm(rows_to_cl(r), [m0.weight], [m0.bias], LINEAR, 1)
+            r = conv_gemm(mish(r), [m2.weight], [m2.bias], LINEAR, 1)
+            r = conv_gemm(mish(r), [m4.weight], [m4.bias], LINEAR, 1)[:, :dim]
+            if use_dropout:
+                if dropout_mask is None:   # same draw as the reference: CPU generator, shape (B, A, 1)
+                    dropout_mask = self.mask_dist.sample(sample_shape=(bsz, n_agents, 1))
+                r = dropout_mask.to(device=dev, dtype=r.dtype).reshape(bsz * n_agents, 1) * r
+            if force_dropout:
+                r = 0 * r
+            parts.append(r)
+        if self.env_ts_condition:
+            assert env_timestep is not None
+            ets = env_timestep.to(dtype=torch.int64)[:, self.history_horizon]
+            ee = self.env_ts_mlp[0].weight[ets]
+            p1, p3 = self.env_ts_mlp[1], self.env_ts_mlp[3]
+            ee = conv_gemm(mish(conv_gemm(rows_to_cl(ee), [p1.weight], [p1.bias], LINEAR, 1)), [p3.weight], [p3.bias],
+                           LINEAR, 1)[:, :dim]
+            parts.append(ee.repeat_interleave(n_agents, dim=0))
+        t = torch.cat(parts, dim=-1)
+        if pad32(t.shape[1]) != t.shape[1]:
+            t = torch.nn.functional.pad(t, (0, pad32(t.shape[1]) - t.shape[1]))
+        return t.contiguous()
+
+    def forward(self, x, time, returns=None, env_timestep=None, attention_masks=None, use_dropout=True,
+                force_dropout=False):
+        raise NotImplementedError("single-agent TemporalUnet.forward is outside the MADiff hot path "
+                                  "(every exp_spec selects SharedConvAttentionDeconv)")
+
+
+# ------------------------------------------------------------------------------------------------
+# ma_temporal.py
+# ------------------------------------------------------------------------------------------------
+class SharedConvAttentionDeconv(nn.Module):
+    """ma_temporal.py:229-418: parameter-shared temporal U-Net + cross-agent attention at the bottleneck and
+    on every skip connection.  forward(x[B,T,A,F], time[B], returns[B,1,A]) -> eps [B,T,A,F] (fp32)."""
+
+    agent_share_parameters = True
+
+    def __init__(self, horizon: int, transition_dim: int, dim: int = 128, history_horizon: int = 0,
+                 dim_mults: Tuple[int] = (1, 2, 4, 8), nhead: int = 4, n_agents: int = 2,
+                 returns_condition: bool = False, env_ts_condition: bool = False, condition_dropout: float = 0.1,
+                 kernel_size: int = 5, residual_attn: bool = True, use_layer_norm: bool = False,
+                 max_path_length: int = 100, use_temporal_attention: bool = True):
+        super().__init__()
+        if use_layer_norm or not use_temporal_attention:
+            raise NotImplementedError("use_layer_norm / use_temporal_attention=False are not selected by any "
+                                      "exp_spec (SURVEY.md section 8f, row F4)")
+        self.n_agents = n_agents
+        self.history_horizon = history_horizon
+        self.use_temporal_attention = use_temporal_attention
+        self.returns_condition = returns_condition
+        self.env_ts_condition = env_ts_condition
+        self.use_layer_norm = use_layer_norm
+        self.transition_dim = transition_dim
+        dims = [transition_dim, *map(lambda m: dim * m, dim_mults)]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        self.net = TemporalUnet(horizon=horizon, history_horizon=history_horizon, transition_dim=transition_dim,
+                                dim=dim, dim_mults=dim_mults, returns_condition=returns_condition,
+                                env_ts_condition=env_ts_condition, condition_dropout=condition_dropout,
+                                max_path_length=max_path_length, kernel_size=kernel_size)
+        attn = [TemporalSelfAttention(in_out[-1][1], in_out[-1][1] // 16, in_out[-1][1] // 4, residual=residual_attn,
+                                      embed_dim=self.net.embed_dim, nheads=nhead)]
+        for d in reversed(in_out):
+            attn.append(TemporalSelfAttention(d[1], d[1] // 16, d[1] // 4, residual=residual_attn,
+                                              embed_dim=self.net.embed_dim, nheads=nhead))
+        self.self_attn = nn.ModuleList(attn)
+
+    # every Linear(Mish(t_emb)) of the live graph, in execution order, evaluated by ONE GEMM per forward
+    def _time_layers(self):
+        net = self.net
+        blocks: List[ResidualTemporalBlock] = []
+        for r1, r2, _ in net.downs:
+            blocks += [r1, r2]
+        blocks += [net.mid_block1, net.mid_block2]
+        for r1, r2, _ in net.ups:
+            blocks += [r1, r2]
+        layers = [b.time_mlp[1] for b in blocks]
+        n_live_attn = 1 + len(net.ups)          # self_attn[len(ups)+1:] are constructed but never called
+        for i in range(n_live_attn):
+            layers += self.self_attn[i].time_layers()
+        return blocks, layers, n_live_attn
+
+    def forward_cl(self, xcl, bsz, t_len, temb):
+        """xcl: cl [(b a) t, pad32(F)]; temb: cl [B*A, pad32(E)].  Returns eps fp32 [B, T, A, F]."""
+        net, A = self.net, self.n_agents
+        blocks, layers, n_attn = self._time_layers()
+        proj_all = conv_gemm(mish(temb), [l.weight for l in layers], [l.bias for l in layers], LINEAR, 1, perm="f32")
+        sizes = [b.out_channels for b in blocks] + [2 * self.self_attn[i].cq + self.self_attn[i].cv for i in range(n_attn)]
+        views = list(ops.SplitCols.apply(proj_all, tuple(sizes)))
+        bproj, aproj = views[: len(blocks)], views[len(blocks):]
+        bi = 0
+        h, t = xcl, t_len
+        skips = []
+        for r1, r2, down in net.downs:
+            h = r1.forward_cl(h, t, bproj[bi]); bi += 1
+            h = r2.forward_cl(h, t, bproj[bi]); bi += 1
+            skips.append((h, t))
+            if isinstance(down, Downsample1d):
+                h, t = down.forward_cl(h, t)
+        h = net.mid_block1.forward_cl(h, t, bproj[bi]); bi += 1
+        h = net.mid_block2.forward_cl(h, t, bproj[bi]); bi += 1
+        h = self.self_attn[0].forward_cl(h, bsz, A, t, aproj[0])
+        for j, (r1, r2, up) in enumerate(net.ups):
+            s, ts = skips.pop()
+            assert ts == t, "skip/upsample length mismatch (horizon must be divisible by 2**(levels-1))"
+            s = self.self_attn[j + 1].forward_cl(s, bsz, A, t, aproj[j + 1])
+            h = r1.forward_cl(h, t, bproj[bi], x2=s); bi += 1
+            h = r2.forward_cl(h, t, bproj[bi]); bi += 1
+            if isinstance(up, Upsample1d):
+                h, t = up.forward_cl(h, t)
+        h = net.final_conv[0].forward_cl(h, t)
+        fc = net.final_conv[1]
+        out = conv_gemm(h, [fc.weight], [fc.bias], CONV1, t, perm=(t, A))
+        return out.reshape(bsz, t, A, self.transition_dim)
+
+    def forward(self, x, time, returns=None, states=None, env_timestep=None, attention_masks=None,
+                use_dropout: bool = True, force_dropout: bool = False, dropout_mask=None, **kwargs):
+        """x : [ batch x horizon x agent x transition ];  returns : [ batch x 1 x agent ]."""
+        assert x.shape[2] == self.n_agents, f"Expected {self.n_agents} agents, but got samples with shape {x.shape}"
+        bsz, t_len = x.shape[0], x.shape[1]
+        temb = self.net.embed(time, returns if self.returns_condition else None, self.n_agents, use_dropout,
+                              force_dropout, dropout_mask, env_timestep)
+        return self.forward_cl(PackTraj.apply(x.to(torch.float32)), bsz, t_len, temb)
+
+    def forward_guided_pair(self, xcl, bsz, t_len, time, returns, env_timestep=None):
+        """Classifier-free-guidance pair as ONE 2B batch (weights are read once): rows [0, B) are the
+        conditional pass (use_dropout=False), rows [B, 2B) the unconditional one (force_dropout=True)
+        (diffusion.py:187-202).  xcl holds the B conditioned inputs; returns (eps_cond, eps_uncond)."""
+        A = self.n_agents
+        tc = self.net.embed(time, returns, A, False, False, None, env_timestep)
+        tu = self.net.embed(time, returns, A, False, True, None, env_timestep)
+        out = self.forward_cl(torch.cat((xcl, xcl), dim=0), 2 * bsz, t_len, torch.cat((tc, tu), dim=0))
+        return out[:bsz], out[bsz:]

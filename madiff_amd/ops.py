@@ -1,0 +1,488 @@
+"""torch.autograd.Functions over the C ABI of libmadiff_hip.so.
+
+Internal activation format ("cl"): a contiguous 2-D tensor [rows = (sequence n, time t), pad32(C)] in the
+build's storage dtype (bf16 or fp32) whose pad columns are zero.  Parameters stay ordinary fp32
+nn.Parameters with the reference's shapes; GEMM-layout copies are cached and refreshed when a
+parameter's version counter changes.  Every op raises if the HIP library is missing (madiff_amd.lib
+fails at import) - there is no PyTorch/CPU fallback on this path.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib
+
+# ------------------------------------------------------------------------------------------------
+# precision ("build") selection
+# ------------------------------------------------------------------------------------------------
+_PRECISION = os.environ.get("MADIFF_PRECISION", "bf16")
+
+
+def set_precision(name: str) -> None:
+    """'bf16' (bf16 storage + bf16 MFMA, fp32 accumulate) or 'fp32' (fp32 storage + exact fp32 MFMA)."""
+    global _PRECISION
+    assert name in ("bf16", "fp32")
+    if name != _PRECISION:
+        _PRECISION = name
+        _PACK_CACHE.clear()
+
+
+def get_precision() -> str:
+    return _PRECISION
+
+
+def act_dtype() -> torch.dtype:
+    return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
+
+
+def _dt() -> int:
+    return lib.BF16 if _PRECISION == "bf16" else lib.F32
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk_cl(x: torch.Tensor):
+    assert x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.dtype == act_dtype(), (x.shape, x.stride(), x.dtype)
+    assert x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing cache
+# ------------------------------------------------------------------------------------------------
+class ConvSpec:
+    """Geometry of one implicit-GEMM layer.  kind: 'conv' (nn.Conv1d [O, I, k]), 'convT' (nn.ConvTranspose1d
+    [I, O, k]) or 'linear' ([O, I])."""
+
+    __slots__ = ("kind", "taps", "stride", "pad", "tr")
+
+    def __init__(self, kind="linear", taps=1, stride=1, pad=0, tr=0):
+        self.kind, self.taps, self.stride, self.pad, self.tr = kind, taps, stride, pad, tr
+
+    def out_len(self, t_in: int) -> int:
+        if self.tr:
+            return (t_in - 1) * self.stride - 2 * self.pad + self.taps
+        return (t_in + 2 * self.pad - self.taps) // self.stride + 1
+
+
+CONV5 = ConvSpec("conv", 5, 1, 2, 0)
+CONV1 = ConvSpec("conv", 1, 1, 0, 0)
+DOWN = ConvSpec("conv", 3, 2, 1, 0)
+UP = ConvSpec("convT", 4, 2, 1, 1)
+LINEAR = ConvSpec("linear", 1, 1, 0, 0)
+
+
+def _strides(kind: str, w: torch.Tensor):
+    """(O, I, so, si, st): element (o, i, tap) of the GEMM view lives at o*so + i*si + tap*st of the parameter."""
+    if kind == "conv":
+        O, I, k = w.shape
+        return O, I, I * k, k, 1
+    if kind == "convT":
+        I, O, k = w.shape
+        return O, I, k, O * k, 1
+    O, I = w.shape
+    return O, I, I, 1, 0
+
+
+_PACK_CACHE: dict = {}
+
+
+def _packed(weights: Sequence[torch.Tensor], spec: ConvSpec, backward: bool) -> torch.Tensor:
+    """GEMM-layout copy of a group of parameters that share the input (concatenated along the output dim).
+
+    forward : [sum O, taps * pad32(I)]        backward (data gradient): [I, taps * pad32(sum O)]
+    """
+    key = (tuple(id(w) for w in weights), spec.kind, spec.taps, backward, _PRECISION)
+    vers = tuple((w._version, w.data_ptr()) for w in weights)
+    ent = _PACK_CACHE.get(key)
+    if ent is not None and ent[0] == vers:
+        return ent[1]
+    dims = [_strides(spec.kind, w) for w in weights]
+    I = dims[0][1]
+    Osum = sum(d[0] for d in dims)
+    if ent is None:
+        shape = (I, spec.taps * pad32(Osum)) if backward else (Osum, spec.taps * pad32(I))
+        buf = torch.zeros(shape, dtype=act_dtype(), device=weights[0].device)
+    else:
+        buf = ent[1]
+    off = 0
+    es = buf.element_size()
+    for w, (O, I_, so, si, st) in zip(weights, dims):
+        assert I_ == I and w.dtype == torch.float32 and w.is_contiguous()
+        if backward:   # rows = i, cols = (tap, o): swap the roles of o and i
+            lib.call("madiff_pack_weight", _dt(), w.data_ptr(), buf.data_ptr(), I, O, spec.taps, si, so, st,
+                     pad32(Osum), off, _stream())
+        else:
+            lib.call("madiff_pack_weight", _dt(), w.data_ptr(), buf.data_ptr() + off * spec.taps * pad32(I) * es, O, I,
+                     spec.taps, so, si, st, pad32(I), 0, _stream())
+        off += O
+    _PACK_CACHE[key] = (vers, buf)
+    return buf
+
+
+def clear_pack_cache() -> None:
+    _PACK_CACHE.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launches
+# ------------------------------------------------------------------------------------------------
+def _gemm(x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, tr, W, nout, npad, bias, rowbias, out, act=0,
+          perm: Optional[Tuple[int, int]] = None):
+    out_f32 = 1 if (out.dtype == torch.float32 and _PRECISION == "bf16") else 0
+    lib.call("madiff_gemm_fwd", _dt(), out_f32, x.data_ptr(), x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0),
+             csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad, tr, W.data_ptr(), W.stride(0), nout, npad,
+             _p(bias), _p(rowbias), 0 if rowbias is None else rowbias.stride(0), out.data_ptr(), out.stride(0), act,
+             perm[0] if perm else 0, perm[1] if perm else 0, _stream())
+
+
+def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout):
+    lib.call("madiff_gemm_wgrad", _dt(), dy.data_ptr(), dy.stride(0), dy.shape[1], x.data_ptr(), x.stride(0), _p(x2),
+             0 if x2 is None else x2.stride(0), csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad, spec.tr,
+             dW.data_ptr(), dW.stride(0), nout, _stream())
+
+
+def pack_traj(x: torch.Tensor, fpad: int, noise=None, t=None, sqrt_ac=None, sqrt_1mac=None, cond=None, mask=None,
+              x_noisy=None) -> torch.Tensor:
+    """[B,T,A,F] fp32 -> cl [(b a) t, fpad] (optionally fused add_noise + inpainting)."""
+    B, T, A, F = x.shape
+    x = x.contiguous()
+    assert x.dtype == torch.float32
+    out = torch.empty(B * A * T, fpad, dtype=act_dtype(), device=x.device)
+    lib.call("madiff_pack_input", _dt(), x.data_ptr(), _p(noise), _p(t), _p(sqrt_ac), _p(sqrt_1mac), _p(cond), _p(mask),
+             out.data_ptr(), _p(x_noisy), B, T, A, F, fpad, _stream())
+    return out
+
+
+def unpack_traj(xcl: torch.Tensor, B, T, A, F) -> torch.Tensor:
+    out = torch.empty(B, T, A, F, dtype=torch.float32, device=xcl.device)
+    lib.call("madiff_unpack_output", _dt(), xcl.data_ptr(), xcl.stride(0), out.data_ptr(), B, T, A, F, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions
+# ------------------------------------------------------------------------------------------------
+class ConvGemm(torch.autograd.Function):
+    """y = conv/linear(x [, x2]) + bias (+ rowbias[n]) for a GROUP of layers sharing the input.
+
+    apply(x, x2, rowbias, spec, t_in, act, perm, n_groups, *weights, *biases) -> cl [M_out, pad32(sum O)]
+    perm = (T, A): fp32 [B*T*A, O] in the reference row order; perm = "f32": fp32 [M_out, pad32(sum O)].
+    """
+
+    @staticmethod
+    def forward(ctx, x, x2, rowbias, spec: ConvSpec, t_in: int, act: int, perm, n_groups: int, *params):
+        weights, biases = params[:n_groups], params[n_groups:]
+        _chk_cl(x)
+        dims = [_strides(spec.kind, w) for w in weights]
+        I = dims[0][1]
+        osum = sum(d[0] for d in dims)
+        c1 = x.shape[1]
+        cin = c1 + (x2.shape[1] if x2 is not None else 0)
+        assert cin == pad32(I) or (x2 is not None and cin == I), (cin, I)
+        M_in = x.shape[0]
+        n_seq = M_in // t_in
+        t_out = spec.out_len(t_in)
+        M = n_seq * t_out
+        W = _packed(weights, spec, False)
+        if len(biases) == 0:
+            bias = None
+        elif len(biases) == 1:
+            bias = biases[0]
+        else:
+            bias = torch.cat([b.detach() for b in biases])
+        out_f32 = perm == "f32"
+        if out_f32:
+            perm = None
+            npad = pad32(osum)
+            out = torch.empty(M, npad, dtype=torch.float32, device=x.device)
+        elif perm is not None:
+            out = torch.empty(M, osum, dtype=torch.float32, device=x.device)
+            npad = osum
+        else:
+            npad = pad32(osum)
+            out = torch.empty(M, npad, dtype=act_dtype(), device=x.device)
+        if x2 is not None:
+            _chk_cl(x2)
+        _gemm(x, x2, c1, M, cin, spec, t_out, t_in, spec.tr, W, osum, npad, bias, rowbias, out, act, perm)
+        ctx.save_for_backward(x, x2, out if act == 1 else None, *weights)
+        ctx.spec, ctx.t_in, ctx.t_out, ctx.act, ctx.perm = spec, t_in, t_out, act, perm
+        ctx.n_groups, ctx.has_bias, ctx.has_rowbias = n_groups, len(biases) > 0, rowbias is not None
+        ctx.dims, ctx.osum, ctx.cin, ctx.c1, ctx.n_seq = dims, osum, cin, c1, n_seq
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, y_act = ctx.saved_tensors[:3]
+        weights = ctx.saved_tensors[3:]
+        spec, t_in, t_out, osum, cin, c1, n_seq = ctx.spec, ctx.t_in, ctx.t_out, ctx.osum, ctx.cin, ctx.c1, ctx.n_seq
+        M = n_seq * t_out
+        M_in = n_seq * t_in
+        npad = pad32(osum)
+        if ctx.perm is not None:       # dy arrives as fp32 [B*T*A, O] in the reference row order
+            Tn, A = ctx.perm
+            dy = pack_traj(dy.reshape(n_seq // A, Tn, A, osum), npad)
+        else:
+            dy = dy.contiguous()
+            if dy.dtype != act_dtype():
+                dy = dy.to(act_dtype())
+        if ctx.act == 1:
+            d2 = torch.empty_like(dy)
+            lib.call("madiff_act_bwd", _dt(), 1, y_act.data_ptr(), dy.data_ptr(), d2.data_ptr(), dy.numel(), _stream())
+            dy = d2
+        needs = ctx.needs_input_grad
+        dx = dx2 = drb = None
+        I = ctx.dims[0][1]
+        # data gradient(s): the same kernel with the tap direction flipped
+        if needs[0] or (x2 is not None and needs[1]):
+            Wb = _packed(weights, spec, True)          # [I, taps * npad]
+            es = Wb.element_size()
+            parts = [(0, c1 if x2 is not None else I, needs[0])]
+            if x2 is not None:
+                parts.append((c1, I - c1, needs[1]))
+            grads = []
+            for (row0, rows, need) in parts:
+                if not need:
+                    grads.append(None)
+                    continue
+                g = torch.empty(M_in, pad32(rows), dtype=act_dtype(), device=dy.device)
+                lib.call("madiff_gemm_fwd", _dt(), 0, dy.data_ptr(), dy.stride(0), None, 0, npad, M_in, npad, spec.taps,
+                         t_in, t_out, spec.stride, spec.pad, 1 - spec.tr, Wb.data_ptr() + row0 * Wb.stride(0) * es,
+                         Wb.stride(0), rows, pad32(rows), None, None, 0, g.data_ptr(), g.stride(0), 0, 0, 0, _stream())
+                grads.append(g)
+            dx = grads[0]
+            if x2 is not None:
+                dx2 = grads[1]
+        # weight gradient (fp32, GEMM layout) -> parameter layout
+        gw: List[Optional[torch.Tensor]] = [None] * ctx.n_groups
+        if any(needs[8 + i] for i in range(ctx.n_groups)):
+            ipad = cin if x2 is None else cin   # K of the forward GEMM (already padded, or exact for a split input)
+            dW = torch.empty(osum, spec.taps * ipad, dtype=torch.float32, device=dy.device)
+            _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum)
+            off = 0
+            for i, (w, (O, I_, so, si, st)) in enumerate(zip(weights, ctx.dims)):
+                if needs[8 + i]:
+                    g = torch.empty_like(w)
+                    lib.call("madiff_unpack_wgrad", dW.data_ptr() + off * dW.stride(0) * 4, g.data_ptr(), O, I_, ipad,
+                             spec.taps, so, si, st, _stream())
+                    gw[i] = g
+                off += O
+        gb: List[Optional[torch.Tensor]] = []
+        if ctx.has_bias:
+            db = torch.zeros(osum, dtype=torch.float32, device=dy.device)
+            lib.call("madiff_colsum", _dt(), dy.data_ptr(), dy.stride(0), db.data_ptr(), M, osum, _stream())
+            off = 0
+            for (O, *_r) in ctx.dims:
+                gb.append(db[off:off + O])
+                off += O
+        if ctx.has_rowbias and needs[2]:
+            drb = torch.empty(n_seq, osum, dtype=torch.float32, device=dy.device)
+            lib.call("madiff_seqsum", _dt(), dy.data_ptr(), dy.stride(0), drb.data_ptr(), drb.stride(0), n_seq, t_out,
+                     osum, _stream())
+        return (dx, dx2, drb, None, None, None, None, None, *gw, *gb)
+
+
+def conv_gemm(x, weights, biases, spec: ConvSpec, t_in: int, x2=None, rowbias=None, act=0, perm=None):
+    weights = list(weights)
+    biases = [] if biases is None else list(biases)
+    if x2 is not None and x.shape[1] % 128 != 0:   # the split-source wgrad tiles need 128-aligned halves
+        x, x2 = torch.cat((x, x2), dim=1), None
+    return ConvGemm.apply(x, x2, rowbias, spec, t_in, act, perm, len(weights), *weights, *biases)
+
+
+class GNMish(torch.autograd.Function):
+    """GroupNorm(8) + Mish (+ rowbias[n] | + residual) on a cl tensor."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, rowbias, res, n_seq: int, t: int, C: int, G: int):
+        _chk_cl(y)
+        cpad = y.shape[1]
+        out = torch.empty_like(y)
+        mean = torch.empty(n_seq * G, dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+        mode = 1 if rowbias is not None else (2 if res is not None else 0)
+        if rowbias is not None:
+            assert rowbias.dtype == torch.float32 and rowbias.stride(1) == 1
+        if res is not None:
+            _chk_cl(res)
+        lib.call("madiff_gn_mish_fwd", _dt(), y.data_ptr(), y.stride(0), out.data_ptr(), out.stride(0), gamma.data_ptr(),
+                 beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n_seq, t, C, cpad, G, 1e-5, mode, _p(rowbias),
+                 0 if rowbias is None else rowbias.stride(0), _p(res), 0 if res is None else res.stride(0), _stream())
+        ctx.save_for_backward(y, gamma, beta, mean, rstd)
+        ctx.geom = (n_seq, t, C, cpad, G, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        n_seq, t, C, cpad, G, mode = ctx.geom
+        dout = dout.contiguous()
+        dy = torch.empty_like(y)
+        dgb = torch.zeros(2, C, dtype=torch.float32, device=y.device)
+        drb = torch.empty(n_seq, C, dtype=torch.float32, device=y.device) if mode == 1 else None
+        lib.call("madiff_gn_mish_bwd", _dt(), y.data_ptr(), y.stride(0), dout.data_ptr(), dout.stride(0), dy.data_ptr(),
+                 dy.stride(0), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dgb[0].data_ptr(),
+                 dgb[1].data_ptr(), _p(drb), C, n_seq, t, C, cpad, G, _stream())
+        return dy, dgb[0], dgb[1], drb, (dout if mode == 2 else None), None, None, None, None
+
+
+class AttnCore(torch.autograd.Function):
+    """softmax over agents of q.k, times v, then x + gamma*out; qkv is the fused projection [M, 2Cq + C]."""
+
+    @staticmethod
+    def forward(ctx, qkv, x, gamma, B, A, T, H, Cq, C, residual: bool):
+        _chk_cl(qkv)
+        _chk_cl(x)
+        out = torch.empty_like(x)
+        if out.shape[1] > C:
+            out[:, C:].zero_()
+        lib.call("madiff_attn_fwd", _dt(), qkv.data_ptr(), qkv.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
+                 out.stride(0), _p(gamma), B, A, T, H, Cq, C, int(residual), _stream())
+        ctx.save_for_backward(qkv, gamma)
+        ctx.geom = (B, A, T, H, Cq, C, residual)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, gamma = ctx.saved_tensors
+        B, A, T, H, Cq, C, residual = ctx.geom
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        if dqkv.shape[1] > 2 * Cq + C:
+            dqkv[:, 2 * Cq + C:].zero_()
+        dgamma = torch.zeros(1, dtype=torch.float32, device=qkv.device) if residual else None
+        lib.call("madiff_attn_bwd", _dt(), qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0),
+                 dqkv.data_ptr(), dqkv.stride(0), _p(gamma), _p(dgamma), B, A, T, H, Cq, C, int(residual), _stream())
+        return dqkv, (dout if residual else None), dgamma, None, None, None, None, None, None, None
+
+
+class Act(torch.autograd.Function):
+    """Mish (kind 2) / ReLU (kind 1) on a cl tensor (pad columns stay zero: both map 0 -> 0)."""
+
+    @staticmethod
+    def forward(ctx, x, kind: int):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        lib.call("madiff_act_fwd", _dt(), kind, x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = torch.empty_like(x)
+        lib.call("madiff_act_bwd", _dt(), ctx.kind, x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream())
+        return dx, None
+
+
+def mish(x):
+    return Act.apply(x, 2)
+
+
+class PackTraj(torch.autograd.Function):
+    """[B,T,A,F] fp32 (reference layout) -> cl [(b a) t, pad32(F)], differentiable."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return pack_traj(x, pad32(x.shape[-1]))
+
+    @staticmethod
+    def backward(ctx, d):
+        B, T, A, F = ctx.shape
+        d = d.contiguous()
+        if d.dtype != act_dtype():
+            d = d.to(act_dtype())
+        return unpack_traj(d, B, T, A, F)
+
+
+class SplitCols(torch.autograd.Function):
+    """Views of column blocks of one fp32 matrix (the fused time-MLP output); backward concatenates."""
+
+    @staticmethod
+    def forward(ctx, big, sizes):
+        ctx.sizes = sizes
+        ctx.meta = (big.shape[0], big.dtype, big.device)
+        outs, off = [], 0
+        for s in sizes:
+            outs.append(big[:, off:off + s])
+            off += s
+        ctx.total = big.shape[1]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n, dt, dev = ctx.meta
+        parts = [g if g is not None else torch.zeros(n, s, dtype=dt, device=dev) for g, s in zip(grads, ctx.sizes)]
+        used = sum(ctx.sizes)
+        if ctx.total > used:
+            parts.append(torch.zeros(n, ctx.total - used, dtype=dt, device=dev))
+        return torch.cat(parts, dim=1), None
+
+
+def sinusoid(ts: torch.Tensor, freq: torch.Tensor, n_agents: int) -> torch.Tensor:
+    """SinusoidalPosEmb for ts[B] (int64), repeated over agents: cl [B*A, 2*half]."""
+    B, half = ts.shape[0], freq.shape[0]
+    assert ts.dtype == torch.int64 and ts.is_contiguous()
+    out = torch.empty(B * n_agents, pad32(2 * half), dtype=act_dtype(), device=ts.device)
+    lib.call("madiff_sinusoid", _dt(), ts.data_ptr(), freq.data_ptr(), out.data_ptr(), out.stride(0), B, n_agents, half,
+             _stream())
+    return out
+
+
+class MaskedStateLoss(torch.autograd.Function):
+    """WeightedStateL2 + loss-mask reduction (helpers.py:243-250, diffusion.py:328-330).
+
+    forward(pred, targ, w[T,A,F], mask[B,T,A] fp32) -> (loss float64 scalar, a0_loss fp32 scalar)
+    """
+
+    @staticmethod
+    def forward(ctx, pred, targ, w, mask):
+        B, T, A, F = pred.shape
+        pred, targ = pred.contiguous(), targ.contiguous()
+        sums = torch.empty(B, 3, dtype=torch.float32, device=pred.device)
+        lib.call("madiff_mse_fwd", pred.data_ptr(), targ.data_ptr(), w.data_ptr(), mask.data_ptr(), sums.data_ptr(), B,
+                 T * A, F, _stream())
+        ctx.save_for_backward(pred, targ, w, mask, sums)
+        s = sums.double()
+        loss = (s[:, 0] / s[:, 1]).sum() / (B * F)
+        a0 = sums[:, 2].sum() / (B * T * A * F)
+        ctx.mark_non_differentiable(a0)
+        return loss, a0
+
+    @staticmethod
+    def backward(ctx, gl, _ga):
+        pred, targ, w, mask, sums = ctx.saved_tensors
+        B, T, A, F = pred.shape
+        go = gl.to(torch.float32).reshape(1).contiguous()
+        dp = torch.empty_like(pred)
+        lib.call("madiff_mse_bwd", pred.data_ptr(), targ.data_ptr(), w.data_ptr(), mask.data_ptr(), sums.data_ptr(),
+                 go.data_ptr(), dp.data_ptr(), B, T * A, F, _stream())
+        return dp, None, None, None
+
+
+def posterior_step(x, eps_c, eps_u, w, z, cond, mask_u8, coef, out, step_ptr=None, step_val=0):
+    lib.call("madiff_posterior_step", x.data_ptr(), eps_c.data_ptr(), _p(eps_u), float(w), _p(z), _p(cond), _p(mask_u8),
+             coef.data_ptr(), _p(step_ptr), int(step_val), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+def inpaint_(x, cond, mask_u8):
+    lib.call("madiff_inpaint", x.data_ptr(), cond.data_ptr(), mask_u8.data_ptr(), x.numel(), _stream())
+    return x

@@ -1,0 +1,268 @@
+"""Kernel-level GPU tests: every C-ABI op (through the autograd Functions) against plain PyTorch fp32 ops of the
+same mathematics, forward and backward, in both builds.  fp32 build tolerance 1e-5, bf16 build 2e-2 (relative to
+the tensor's max magnitude)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 2e-5, "bf16": 2e-2}
+
+
+@pytest.fixture(params=["fp32", "bf16"])
+def prec(request):
+    from madiff_amd import ops
+    ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision("bf16")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _q(x, prec):
+    """Round test inputs to the storage type so the comparison isolates the kernel's arithmetic."""
+    return x.to(torch.bfloat16).float() if prec == "bf16" else x
+
+
+@pytest.mark.parametrize("case", ["conv5", "conv5_wide", "down", "down_odd", "up", "conv1", "linear_groups", "first_layer"])
+def test_conv_gemm_fwd_bwd(prec, case):
+    from madiff_amd import modules as M, ops
+    dev = _dev()
+    cfgs = {  # N, T, Cin, Cout(s), spec
+        "conv5": (5, 12, 64, [96], ops.CONV5), "conv5_wide": (9, 6, 256, [160], ops.CONV5),
+        "down": (4, 14, 32, [32], ops.DOWN), "down_odd": (3, 7, 32, [32], ops.DOWN), "up": (4, 7, 64, [64], ops.UP),
+        "conv1": (3, 24, 128, [40], ops.CONV1), "linear_groups": (37, 1, 64, [16, 48, 24], ops.LINEAR),
+        "first_layer": (6, 24, 18, [128], ops.CONV5),
+    }
+    N, T, Cin, Couts, spec = cfgs[case]
+    k = spec.taps
+    x = _q(_rand(N, Cin, T, seed=1), prec).to(dev).requires_grad_(True)
+    ws, bs = [], []
+    for i, co in enumerate(Couts):
+        shape = (co, Cin, k) if spec.kind == "conv" else ((Cin, co, k) if spec.kind == "convT" else (co, Cin))
+        ws.append(_q(_rand(*shape, seed=10 + i, scale=1 / math.sqrt(Cin * k)), prec).to(dev).requires_grad_(True))
+        bs.append(_rand(co, seed=20 + i, scale=0.1).to(dev).requires_grad_(True))
+    # reference
+    refs = []
+    for w, b in zip(ws, bs):
+        if spec.kind == "conv":
+            refs.append(F.conv1d(x, w, b, stride=spec.stride, padding=spec.pad))
+        elif spec.kind == "convT":
+            refs.append(F.conv_transpose1d(x, w, b, stride=spec.stride, padding=spec.pad))
+        else:
+            refs.append(F.linear(x[:, :, 0], w, b)[:, :, None])
+    ref = torch.cat(refs, dim=1)
+    gy = _q(_rand(*ref.shape, seed=3), prec).to(dev)
+    gref = torch.autograd.grad(ref, [x] + ws + bs, gy)
+    # ours
+    x2 = x.detach().clone().requires_grad_(True)
+    ws2 = [w.detach().clone().requires_grad_(True) for w in ws]
+    bs2 = [b.detach().clone().requires_grad_(True) for b in bs]
+    y = ops.conv_gemm(M.to_cl(x2), ws2, bs2, spec, T)
+    T2 = spec.out_len(T)
+    out = M.from_cl(y, N, T2, sum(Couts))
+    assert out.shape == ref.shape
+    assert rel_err(out.detach().cpu(), ref.detach().cpu()) < TOL[prec]
+    if y.shape[1] > sum(Couts):
+        assert float(y[:, sum(Couts):].abs().max()) == 0.0      # zero-padding invariant
+    gours = torch.autograd.grad(out, [x2] + ws2 + bs2, gy)
+    for a, b, name in zip(gours, gref, ["dx"] + ["dw"] * len(ws) + ["db"] * len(bs)):
+        assert a.shape == b.shape
+        assert rel_err(a.cpu(), b.cpu()) < TOL[prec] * (3 if prec == "bf16" else 1), name
+
+
+def test_conv_gemm_split_source(prec):
+    """conv over cat((x, skip), channels) without materialising the concat (ma_temporal.py:405)."""
+    from madiff_amd import modules as M, ops
+    dev = _dev()
+    N, T, C1, C2, Co = 7, 6, 128, 128, 64
+    a = _q(_rand(N, C1, T, seed=1), prec).to(dev).requires_grad_(True)
+    b = _q(_rand(N, C2, T, seed=2), prec).to(dev).requires_grad_(True)
+    w = _q(_rand(Co, C1 + C2, 5, seed=3, scale=0.03), prec).to(dev).requires_grad_(True)
+    bias = _rand(Co, seed=4, scale=0.1).to(dev).requires_grad_(True)
+    ref = F.conv1d(torch.cat((a, b), dim=1), w, bias, padding=2)
+    gy = _q(_rand(*ref.shape, seed=5), prec).to(dev)
+    gref = torch.autograd.grad(ref, [a, b, w, bias], gy)
+    a2, b2, w2, bias2 = [t.detach().clone().requires_grad_(True) for t in (a, b, w, bias)]
+    y = ops.conv_gemm(M.to_cl(a2), [w2], [bias2], ops.CONV5, T, x2=M.to_cl(b2))
+    out = M.from_cl(y, N, T, Co)
+    assert rel_err(out.detach().cpu(), ref.detach().cpu()) < TOL[prec]
+    for g1, g0 in zip(torch.autograd.grad(out, [a2, b2, w2, bias2], gy), gref):
+        assert rel_err(g1.cpu(), g0.cpu()) < TOL[prec] * (3 if prec == "bf16" else 1)
+
+
+@pytest.mark.parametrize("mode", ["plain", "temb", "res"])
+@pytest.mark.parametrize("shape", [(6, 24, 16), (5, 12, 64), (4, 6, 1024), (3, 7, 128)])
+def test_gn_mish(prec, mode, shape):
+    from madiff_amd import modules as M, ops
+    dev = _dev()
+    N, T, C = shape
+    x = _q(_rand(N, C, T, seed=1, scale=2.0), prec).to(dev).requires_grad_(True)
+    gamma = (_rand(C, seed=2) * 0.5 + 1).to(dev).requires_grad_(True)
+    beta = _rand(C, seed=3, scale=0.3).to(dev).requires_grad_(True)
+    temb = _rand(N, C, seed=4).to(dev).requires_grad_(True)
+    res = _q(_rand(N, C, T, seed=5), prec).to(dev).requires_grad_(True)
+    ref = F.mish(F.group_norm(x, 8, gamma, beta, eps=1e-5))
+    ins = [x, gamma, beta]
+    if mode == "temb":
+        ref = ref + temb[:, :, None]; ins.append(temb)
+    elif mode == "res":
+        ref = ref + res; ins.append(res)
+    gy = _q(_rand(*ref.shape, seed=6), prec).to(dev)
+    gref = torch.autograd.grad(ref, ins, gy)
+    x2, g2, b2, t2, r2 = [t.detach().clone().requires_grad_(True) for t in (x, gamma, beta, temb, res)]
+    out = ops.GNMish.apply(M.to_cl(x2), g2, b2, t2 if mode == "temb" else None, M.to_cl(r2) if mode == "res" else None,
+                           N, T, C, 8)
+    o = M.from_cl(out, N, T, C)
+    assert rel_err(o.detach().cpu(), ref.detach().cpu()) < TOL[prec]
+    ins2 = [x2, g2, b2] + ([t2] if mode == "temb" else []) + ([r2] if mode == "res" else [])
+    for a, b in zip(torch.autograd.grad(o, ins2, gy), gref):
+        assert rel_err(a.cpu(), b.cpu()) < TOL[prec] * (3 if prec == "bf16" else 2)
+
+
+@pytest.mark.parametrize("geom", [(3, 3, 6, 64), (2, 8, 6, 128), (2, 4, 12, 512)])
+def test_attention_core(prec, geom):
+    from madiff_amd import modules as M, ops
+    dev = _dev()
+    B, A, T, C = geom
+    H, Cq = 4, (C // 16) * 4
+    W = 2 * Cq + C
+    qkv = _q(_rand(B * A * T, W, seed=1), prec).to(dev).requires_grad_(True)
+    x = _q(_rand(B * A * T, C, seed=2), prec).to(dev).requires_grad_(True)
+    gamma = torch.tensor([0.7], device=dev, requires_grad=True)
+
+    def ref_fn(qkv, x, gamma):
+        def heads(m, c):     # [(b a) t, c] -> h b a (d t)
+            d = c // H
+            return m.reshape(B, A, T, H, d).permute(3, 0, 1, 4, 2).reshape(H, B, A, d * T)
+        q, k, v = heads(qkv[:, :Cq], Cq), heads(qkv[:, Cq:2 * Cq], Cq), heads(qkv[:, 2 * Cq:], C)
+        att = torch.softmax(torch.einsum("hbif,hbjf->hbij", q, k) / math.sqrt(q.shape[-1]), dim=-1)
+        o = torch.einsum("hbij,hbjf->hbif", att, v)                       # h b a (d t)
+        o = o.reshape(H, B, A, C // H, T).permute(1, 2, 4, 0, 3).reshape(B * A * T, C)
+        return x + gamma * o
+
+    ref = ref_fn(qkv, x, gamma)
+    gy = _q(_rand(*ref.shape, seed=3), prec).to(dev)
+    gref = torch.autograd.grad(ref, [qkv, x, gamma], gy)
+    q2, x2, g2 = [t.detach().clone().requires_grad_(True) for t in (qkv, x, gamma)]
+    out = ops.AttnCore.apply(q2.to(ops.act_dtype()), x2.to(ops.act_dtype()), g2, B, A, T, H, Cq, C, True)
+    assert rel_err(out.detach().float().cpu(), ref.detach().cpu()) < TOL[prec]
+    for a, b in zip(torch.autograd.grad(out, [q2, x2, g2], gy.to(ops.act_dtype())), gref):
+        assert rel_err(a.float().cpu(), b.cpu()) < TOL[prec] * (3 if prec == "bf16" else 2)
+
+
+def test_pack_unpack_noise_inpaint(prec):
+    from madiff_amd import ops
+    from madiff_amd.schedulers import DDPMScheduler
+    dev = _dev()
+    B, T, A, Fd = 3, 6, 4, 18
+    x = _rand(B, T, A, Fd, seed=1).to(dev)
+    cl = ops.pack_traj(x, 32)
+    assert cl.shape == (B * A * T, 32) and float(cl[:, Fd:].abs().max()) == 0
+    back = ops.unpack_traj(cl, B, T, A, Fd)
+    assert rel_err(back.cpu(), x.cpu()) < (1e-7 if prec == "fp32" else 8e-3)
+    s = DDPMScheduler(num_train_timesteps=200)
+    noise = _rand(B, T, A, Fd, seed=2).to(dev)
+    t = torch.tensor([0, 57, 199], device=dev)
+    cond = _rand(B, T, A, Fd, seed=3).to(dev)
+    mask = (torch.rand(B, T, A, Fd, generator=torch.Generator().manual_seed(4)) < 0.3).to(dev)
+    xn = torch.empty_like(x)
+    ops.pack_traj(x, 32, noise=noise, t=t, sqrt_ac=(s.alphas_cumprod ** 0.5).to(dev),
+                  sqrt_1mac=((1 - s.alphas_cumprod) ** 0.5).to(dev), cond=cond, mask=mask.to(torch.uint8), x_noisy=xn)
+    ref = torch.where(mask, cond, s.add_noise(x, noise, t))
+    assert rel_err(xn.cpu(), ref.cpu()) < 1e-6
+
+
+def test_posterior_and_mse():
+    from madiff_amd import ops
+    from madiff_amd.schedulers import DDIMScheduler, DDPMScheduler
+    from oracle import madiff_oracle as O
+    dev = _dev()
+    B, T, A, Fd = 2, 6, 3, 18
+    x, ec, eu, z, cond = [_rand(B, T, A, Fd, seed=i, scale=1.5).to(dev) for i in range(5)]
+    mask = (torch.rand(B, T, A, Fd, generator=torch.Generator().manual_seed(9)) < 0.2).to(dev)
+    s, o = DDPMScheduler(num_train_timesteps=200), O.DDPMSchedule(200)
+    coef = s.coef_table().to(dev)
+    for i, t in enumerate(s.timesteps.tolist()):
+        if t not in (199, 100, 1, 0):
+            continue
+        out = torch.empty_like(x)
+        ops.posterior_step(x, ec, eu, 1.2, z, cond, mask.to(torch.uint8), coef, out, step_val=i)
+        eps = eu + 1.2 * (ec - eu)
+        ref = torch.where(mask.cpu(), cond.cpu(), o.step(eps.cpu(), t, x.cpu(), z.cpu()))
+        assert rel_err(out.cpu(), ref) < 2e-6, t
+    d = DDIMScheduler(num_train_timesteps=200); d.set_timesteps(15)
+    od = O.DDIMSchedule(200, 15)
+    cd = d.coef_table().to(dev)
+    state = torch.tensor([3], dtype=torch.int32, device=dev)
+    out = torch.empty_like(x)
+    ops.posterior_step(x, ec, None, 0.0, None, None, None, cd, out, step_ptr=state)
+    assert rel_err(out.cpu(), od.step(ec.cpu(), d.timesteps[3].item(), x.cpu())) < 2e-6
+    # masked weighted MSE, forward + backward, against the reference formula (float64 masks)
+    pred = _rand(B, T, A, Fd, seed=11).to(dev).requires_grad_(True)
+    targ = _rand(B, T, A, Fd, seed=12).to(dev)
+    w = (torch.rand(T, A, Fd, generator=torch.Generator().manual_seed(13)) + 0.5).to(dev)
+    m = (torch.rand(B, T, A, 1, generator=torch.Generator().manual_seed(14)) < 0.7).double().to(dev)
+    l = (pred - targ) ** 2 * w
+    ref = ((l * m).mean(dim=[1, 2]) / m.mean(dim=[1, 2])).mean()
+    gref, = torch.autograd.grad(ref, pred)
+    p2 = pred.detach().clone().requires_grad_(True)
+    loss, a0 = ops.MaskedStateLoss.apply(p2, targ, w, m.float().reshape(B, T, A).contiguous())
+    assert loss.dtype == torch.float64 and abs(loss.item() - ref.item()) < 1e-6 * abs(ref.item())
+    assert abs(a0.item() - l.mean().item()) < 2e-6 * abs(l.mean().item())
+    g2, = torch.autograd.grad(loss, p2)
+    assert rel_err(g2.cpu(), gref.cpu()) < 1e-5
+
+
+def test_sinusoid_and_activations(prec):
+    from madiff_amd import modules as M, ops
+    from oracle import madiff_oracle as O
+    dev = _dev()
+    emb = M.SinusoidalPosEmb(128)
+    t = torch.tensor([[0, 1, 7], [100, 199, 42]], device=dev)
+    y = emb(t)
+    assert rel_err(y.cpu(), O.sinusoidal_embedding(t.cpu(), 128)) < (2e-6 if prec == "fp32" else 8e-3)
+    x = _q(_rand(33, 64, seed=1, scale=4), prec).to(dev).requires_grad_(True)
+    ref = F.mish(x)
+    gy = _q(_rand(33, 64, seed=2), prec).to(dev)
+    gref, = torch.autograd.grad(ref, x, gy)
+    x2 = x.detach().clone().requires_grad_(True)
+    out = ops.mish(x2.to(ops.act_dtype()))
+    assert rel_err(out.detach().float().cpu(), ref.detach().cpu()) < TOL[prec]
+    g2, = torch.autograd.grad(out, x2, gy.to(ops.act_dtype()))
+    assert rel_err(g2.cpu(), gref.cpu()) < TOL[prec]
+
+
+def test_adam_ema_kernel():
+    from madiff_amd import lib
+    dev = _dev()
+    n = 100003
+    p = _rand(n, seed=1).to(dev); g = _rand(n, seed=2).to(dev)
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=2e-4)
+    m = torch.zeros_like(p); v = torch.zeros_like(p); ema = p.clone()
+    ema_ref = p.clone()
+    for step in range(1, 4):
+        ref_p.grad = g.clone() * step
+        opt.step()
+        ema_ref = 0.995 * ema_ref + 0.005 * ref_p.detach()
+        gs = g * step
+        lib.call("madiff_adam_ema", p.data_ptr(), gs.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(), n, 2e-4,
+                 0.9, 0.999, 1e-8, 1 - 0.9 ** step, math.sqrt(1 - 0.999 ** step), 1.0, 1, 0.995,
+                 torch.cuda.current_stream().cuda_stream)
+    assert rel_err(p.cpu(), ref_p.detach().cpu()) < 1e-6
+    assert rel_err(ema.cpu(), ema_ref.cpu()) < 1e-6
