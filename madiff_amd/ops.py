@@ -9,6 +9,7 @@ fails at import) - there is no PyTorch/CPU fallback on this path.
 from __future__ import annotations
 
 import os
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -97,6 +98,14 @@ def _strides(kind: str, w: torch.Tensor):
 
 
 _PACK_CACHE: dict = {}
+_EPOCH = 0
+
+
+def params_changed() -> None:
+    """Tell the pack cache that parameter memory was written behind autograd's back (e.g. by the fused
+    Adam kernel, which does not bump torch's version counters)."""
+    global _EPOCH
+    _EPOCH += 1
 
 
 def _packed(weights: Sequence[torch.Tensor], spec: ConvSpec, backward: bool) -> torch.Tensor:
@@ -105,8 +114,10 @@ def _packed(weights: Sequence[torch.Tensor], spec: ConvSpec, backward: bool) -> 
     forward : [sum O, taps * pad32(I)]        backward (data gradient): [I, taps * pad32(sum O)]
     """
     key = (tuple(id(w) for w in weights), spec.kind, spec.taps, backward, _PRECISION)
-    vers = tuple((w._version, w.data_ptr()) for w in weights)
+    vers = (_EPOCH,) + tuple((w._version, w.data_ptr()) for w in weights)
     ent = _PACK_CACHE.get(key)
+    if ent is not None and not all(r() is w for r, w in zip(ent[2], weights)):
+        ent = None                      # id() of a dead parameter was reused by a new object
     if ent is not None and ent[0] == vers:
         return ent[1]
     dims = [_strides(spec.kind, w) for w in weights]
@@ -128,7 +139,9 @@ def _packed(weights: Sequence[torch.Tensor], spec: ConvSpec, backward: bool) -> 
             lib.call("madiff_pack_weight", _dt(), w.data_ptr(), buf.data_ptr() + off * spec.taps * pad32(I) * es, O, I,
                      spec.taps, so, si, st, pad32(I), 0, _stream())
         off += O
-    _PACK_CACHE[key] = (vers, buf)
+    refs = ent[2] if ent is not None else tuple(weakref.ref(w, lambda _r, k=key: _PACK_CACHE.pop(k, None))
+                                                for w in weights)
+    _PACK_CACHE[key] = (vers, buf, refs)
     return buf
 
 
