@@ -150,6 +150,40 @@ def clear_pack_cache() -> None:
 
 
 # ------------------------------------------------------------------------------------------------
+# optional per-launch timing with HIP events on the launch stream (bench.py's roofline figures)
+# ------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """Collects (kernel name, algorithmic FLOPs, start event, stop event) per launch while installed."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _timed(name: str, flops: float, launch):
+    if TIMER is None:
+        launch()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    TIMER.records.append((name, flops, e0, e1))
+
+
+# ------------------------------------------------------------------------------------------------
 # raw launches
 # ------------------------------------------------------------------------------------------------
 def _gemm(x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, tr, W, nout, npad, bias, rowbias, out, act=0,
@@ -229,7 +263,11 @@ class ConvGemm(torch.autograd.Function):
             out = torch.empty(M, npad, dtype=act_dtype(), device=x.device)
         if x2 is not None:
             _chk_cl(x2)
-        _gemm(x, x2, c1, M, cin, spec, t_out, t_in, spec.tr, W, osum, npad, bias, rowbias, out, act, perm)
+        # algorithmic FLOPs of this layer = 2 * dense MACs (the count SURVEY.md section 8d uses); the data- and
+        # weight-gradient launches of the same layer do the same number of MACs
+        ctx.flops = flops = 2.0 * (M_in if spec.tr else M) * osum * I * spec.taps
+        _timed("gemm_fwd_kernel", flops,
+               lambda: _gemm(x, x2, c1, M, cin, spec, t_out, t_in, spec.tr, W, osum, npad, bias, rowbias, out, act, perm))
         ctx.save_for_backward(x, x2, out if act == 1 else None, *weights)
         ctx.spec, ctx.t_in, ctx.t_out, ctx.act, ctx.perm = spec, t_in, t_out, act, perm
         ctx.n_groups, ctx.has_bias, ctx.has_rowbias = n_groups, len(biases) > 0, rowbias is not None
@@ -271,9 +309,10 @@ class ConvGemm(torch.autograd.Function):
                     grads.append(None)
                     continue
                 g = torch.empty(M_in, pad32(rows), dtype=act_dtype(), device=dy.device)
-                lib.call("madiff_gemm_fwd", _dt(), 0, dy.data_ptr(), dy.stride(0), None, 0, npad, M_in, npad, spec.taps,
-                         t_in, t_out, spec.stride, spec.pad, 1 - spec.tr, Wb.data_ptr() + row0 * Wb.stride(0) * es,
-                         Wb.stride(0), rows, pad32(rows), None, None, 0, g.data_ptr(), g.stride(0), 0, 0, 0, _stream())
+                _timed("gemm_fwd_kernel", ctx.flops * rows / I, lambda: lib.call(
+                    "madiff_gemm_fwd", _dt(), 0, dy.data_ptr(), dy.stride(0), None, 0, npad, M_in, npad, spec.taps,
+                    t_in, t_out, spec.stride, spec.pad, 1 - spec.tr, Wb.data_ptr() + row0 * Wb.stride(0) * es,
+                    Wb.stride(0), rows, pad32(rows), None, None, 0, g.data_ptr(), g.stride(0), 0, 0, 0, _stream()))
                 grads.append(g)
             dx = grads[0]
             if x2 is not None:
@@ -283,7 +322,7 @@ class ConvGemm(torch.autograd.Function):
         if any(needs[8 + i] for i in range(ctx.n_groups)):
             ipad = cin if x2 is None else cin   # K of the forward GEMM (already padded, or exact for a split input)
             dW = torch.empty(osum, spec.taps * ipad, dtype=torch.float32, device=dy.device)
-            _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum)
+            _timed("gemm_wgrad_kernel", ctx.flops, lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum))
             off = 0
             for i, (w, (O, I_, so, si, st)) in enumerate(zip(weights, ctx.dims)):
                 if needs[8 + i]:

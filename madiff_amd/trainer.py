@@ -1,0 +1,207 @@
+"""Data-parallel optimizer step for the denoiser: flat parameter/gradient buffers, bucketed gradient all-reduce
+(RCCL over xGMI through torch.distributed) overlapped with backward, and one fused Adam(+EMA) launch.
+
+Reference behaviour reproduced (diffuser/utils/training.py): Adam(lr, torch defaults) over
+``diffusion.parameters()`` (:109), ``gradient_accumulate_every`` micro-batches each scaled by 1/accumulate
+(:147-152), EMA every ``update_ema_every`` steps -- plain copy before ``step_start_ema`` then a lerp with
+``ema_decay`` (:20-39,134-138).  The reference is single-process; the data-parallel part is new and changes no
+single-process result: world_size == 1 performs no collective.
+
+Layout: every parameter that can receive a gradient is re-pointed into ONE flat fp32 buffer (forward/registration
+order) and its ``.grad`` into a second flat buffer, so the optimizer is a single kernel over 64 M elements and a
+gradient bucket is a contiguous slice.  Parameters that never receive a gradient (``self_attn.3.*`` of the
+reference architecture) are detected on the first backward and left out, exactly as torch.optim.Adam
+skips ``grad is None``.  Buckets are cut in REVERSE registration order (the order backward produces them); each is
+all-reduced on a side stream as soon as all of its gradients of the last micro-batch have been accumulated.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import lib, ops
+
+
+class FlatAdamEMA:
+    def __init__(self, module: torch.nn.Module, ema_module: Optional[torch.nn.Module] = None, lr: float = 2e-4,
+                 betas=(0.9, 0.999), eps: float = 1e-8, ema_decay: float = 0.995, bucket_mb: float = 64.0,
+                 process_group=None, use_hip_kernel: Optional[bool] = None):
+        self.module, self.ema_module = module, ema_module
+        self.lr, self.betas, self.eps, self.ema_decay = lr, betas, eps, ema_decay
+        self.step_count = 0
+        self.bucket_bytes = int(bucket_mb * 2 ** 20)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.params: List[torch.nn.Parameter] = []
+        self.names: List[str] = []
+        self.flat_p = self.flat_g = self.flat_m = self.flat_v = self.flat_ema = None
+        self.buckets: List[dict] = []
+        self._hooks = []
+        self._sync_this_backward = True
+        self._comm_stream = None
+        self.use_hip = use_hip_kernel
+        self.grad_scale = 1.0
+
+    # ------------------------------------------------------------------ setup after the first backward
+    def _materialise(self):
+        """Called once, after a backward pass has shown which parameters are live."""
+        named = [(n, p) for n, p in self.module.named_parameters() if p.requires_grad and p.grad is not None]
+        assert named, "run one backward pass before the first optimizer step"
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        dev = self.params[0].device
+        if self.use_hip is None:
+            self.use_hip = dev.type == "cuda"
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4          # keep every slice 16-byte aligned
+        self.offsets, self.total = offs, total
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        ema_named: Dict[str, torch.nn.Parameter] = dict(self.ema_module.named_parameters()) if self.ema_module is not None else {}
+        if self.ema_module is not None:
+            self.flat_ema = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for n, p, o in zip(self.names, self.params, offs):
+                k = p.numel()
+                self.flat_p[o:o + k].copy_(p.detach().reshape(-1))
+                self.flat_g[o:o + k].copy_(p.grad.reshape(-1))
+                p.data = self.flat_p[o:o + k].view_as(p)
+                p.grad = self.flat_g[o:o + k].view_as(p)
+                if self.ema_module is not None:
+                    e = ema_named[n]
+                    self.flat_ema[o:o + k].copy_(e.detach().reshape(-1))
+                    e.data = self.flat_ema[o:o + k].view_as(e)
+        ops.params_changed()
+        # buckets: contiguous slices, cut from the END of the flat buffer (first gradients backward produces)
+        self.buckets = []
+        hi = total
+        idx = len(self.params) - 1
+        while idx >= 0:
+            members = []
+            lo = hi
+            while idx >= 0 and (not members or (hi - offs[idx]) * 4 <= self.bucket_bytes):
+                members.append(idx)
+                lo = offs[idx]
+                idx -= 1
+            self.buckets.append({"lo": lo, "hi": hi, "members": members, "pending": len(members), "work": None})
+            hi = lo
+        self._bucket_of = {}
+        for b in self.buckets:
+            for i in b["members"]:
+                self._bucket_of[i] = b
+        if self.world > 1:
+            if dev.type == "cuda":
+                self._comm_stream = torch.cuda.Stream(device=dev)
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            if not self._sync_this_backward:
+                return
+            b = self._bucket_of[i]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._launch_bucket(b)
+        return hook
+
+    def _launch_bucket(self, b):
+        g = self.flat_g[b["lo"]:b["hi"]]
+        if self._comm_stream is not None:
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
+            b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    # ------------------------------------------------------------------ per-step API
+    def zero_grad(self):
+        if self.flat_g is not None:
+            self.flat_g.zero_()
+        else:
+            for p in self.module.parameters():
+                p.grad = None
+
+    def set_sync(self, flag: bool):
+        """Only the last micro-batch of an accumulation group triggers the all-reduce (no_sync equivalent)."""
+        self._sync_this_backward = flag
+        if flag:
+            for b in self.buckets:
+                b["pending"] = len(b["members"])
+                b["work"] = None
+
+    def _finish_allreduce(self):
+        if self.world <= 1:
+            return
+        if not self._hooks:            # first step: buffers were created after backward -> reduce everything now
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        for b in self.buckets:
+            if b["work"] is None:      # a bucket whose hooks did not all fire (should not happen) -> reduce now
+                self._launch_bucket(b)
+            b["work"].wait()
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def step(self, do_ema: int = 0):
+        """do_ema: 0 none, 1 lerp with ema_decay, 2 copy (reference: before step_start_ema)."""
+        first = self.flat_p is None
+        if first:
+            self._materialise()
+        self._finish_allreduce()
+        self.step_count += 1
+        b1, b2 = self.betas
+        bc1 = 1 - b1 ** self.step_count
+        bc2s = math.sqrt(1 - b2 ** self.step_count)
+        scale = self.grad_scale / self.world
+        if self.ema_module is None:
+            do_ema = 0
+        if self.use_hip:
+            lib.call("madiff_adam_ema", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                     self.flat_v.data_ptr(), None if self.flat_ema is None else self.flat_ema.data_ptr(), self.total,
+                     self.lr, b1, b2, self.eps, bc1, bc2s, scale, do_ema, self.ema_decay,
+                     torch.cuda.current_stream().cuda_stream)
+            ops.params_changed()
+        else:   # host arithmetic for the gloo/CPU tests of the data-parallel machinery only
+            with torch.no_grad():
+                g = self.flat_g * scale
+                self.flat_m.mul_(b1).add_(g, alpha=1 - b1)
+                self.flat_v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (self.flat_v.sqrt() / bc2s).add_(self.eps)
+                self.flat_p.addcdiv_(self.flat_m, denom, value=-self.lr / bc1)
+                if do_ema == 1:
+                    self.flat_ema.mul_(self.ema_decay).add_(self.flat_p, alpha=1 - self.ema_decay)
+                elif do_ema == 2:
+                    self.flat_ema.copy_(self.flat_p)
+
+    def broadcast_parameters(self, src: int = 0):
+        """Make every rank start from rank `src`'s weights (the reference has one process; DP needs this once)."""
+        if self.world <= 1:
+            return
+        for p in self.module.parameters():
+            dist.broadcast(p.data, src=src, group=self.pg)
+        if self.ema_module is not None:
+            for p in self.ema_module.parameters():
+                dist.broadcast(p.data, src=src, group=self.pg)
+        ops.params_changed()
+
+
+def train_step(diffusion, opt: FlatAdamEMA, batches, do_ema: int = 0):
+    """One optimizer step over `len(batches)` micro-batches (training.py:147-158).  Returns the last (loss, infos)."""
+    n = len(batches)
+    out = None
+    for i, batch in enumerate(batches):
+        opt.set_sync(i == n - 1)
+        loss, infos = diffusion.loss(**batch)
+        (loss / n).backward()
+        out = (loss.detach(), infos)
+    opt.step(do_ema)
+    opt.zero_grad()
+    return out
