@@ -56,16 +56,18 @@ int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void*
 int madiff_pack_weight(int dtype, const float* src, void* dst, int O, int I, int taps, long so, long si, long st,
                        int dst_ld, int dst_off, madiff_stream_t stream);
 int madiff_unpack_wgrad(const float* packed, float* grad, int O, int I, int Ipad, int taps, long so, long si, long st,
-                        madiff_stream_t stream);
+                        int accumulate, madiff_stream_t stream);
 
 /* Fused GroupNorm(G) + Mish + {mode 1: + rowbias[n, c] (timestep embedding), mode 2: + res[m, c] (residual)}.
  * Replaces helpers.py:67-71 plus the adds of temporal.py:197-200.  mean/rstd [N, G] are saved for backward. */
 int madiff_gn_mish_fwd(int dtype, const void* y, int ldy, void* out, int ldo, const float* gamma, const float* beta,
                        float* mean, float* rstd, int N, int T, int C, int Cpad, int G, float eps, int mode,
                        const float* rowbias, int ldrb, const void* res, int ldr, madiff_stream_t stream);
-/* Backward of the above.  dgamma/dbeta [C] are accumulated (caller zeroes); drowbias [N, ldrb] may be null. */
+/* Backward of the above.  dgamma/dbeta/dbias [C] are ACCUMULATED with atomics (caller zeroes them or passes live
+ * gradient buffers); dbias (may be null) is the gradient of the bias of the conv feeding the norm (sum_m dy);
+ * drowbias [N, ldrb] (may be null) is stored. */
 int madiff_gn_mish_bwd(int dtype, const void* y, int ldy, const void* dout, int ldd, void* dy, int ldg, const float* gamma,
-                       const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                       const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias,
                        float* drowbias, int ldrb, int N, int T, int C, int Cpad, int G, madiff_stream_t stream);
 
 /* Cross-agent attention core on the fused projection matrix qkv = [q | k | v] ([M, 2*Cq + C]):

@@ -129,6 +129,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   }
 }
 
+extern "C" int madiff_attn_fwd_v2(int dtype, const void* qkv, int ldq, const void* x, int ldx, void* out, int ldo, const float* gamma,
+                                  int B, int A, int T, int H, int Cq, int C, float scale, int residual, hipStream_t stream);
+extern "C" int madiff_attn_bwd_v2(int dtype, const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg,
+                                  const float* gamma, float* dgamma, int B, int A, int T, int H, int Cq, int C, float scale,
+                                  int residual, hipStream_t stream);
+
 static int att_check(int B, int A, int T, int H, int Cq, int C) {
   return (B > 0 && A > 0 && T > 0 && H > 0 && Cq > 0 && C > 0 && Cq % H == 0 && C % H == 0 &&
           H * A * A <= ATT_MAX_ENT) ? 0 : -1;
@@ -139,6 +145,10 @@ extern "C" int madiff_attn_fwd(int dtype, const void* qkv, int ldq, const void* 
                                hipStream_t stream) {
   if (att_check(B, A, T, H, Cq, C) || ldq < 2 * Cq + C || ldx < C || ldo < C || (residual && !gamma)) return -1;
   float scale = 1.0f / sqrtf((float)(Cq / H) * (float)T);
+  {
+    int rc = madiff_attn_fwd_v2(dtype, qkv, ldq, x, ldx, out, ldo, gamma, B, A, T, H, Cq, C, scale, residual, stream);
+    if (rc <= 0) return rc;
+  }
   int blocks = B < 4096 ? B : 4096;
   if (dtype == MADIFF_BF16)
     hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)qkv, ldq,
@@ -157,6 +167,10 @@ extern "C" int madiff_attn_bwd(int dtype, const void* qkv, int ldq, const void* 
   if (att_check(B, A, T, H, Cq, C) || ldq < 2 * Cq + C || ldd < C || ldg < 2 * Cq + C || (residual && (!gamma || !dgamma)))
     return -1;
   float scale = 1.0f / sqrtf((float)(Cq / H) * (float)T);
+  {
+    int rc = madiff_attn_bwd_v2(dtype, qkv, ldq, dout, ldd, dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual, stream);
+    if (rc <= 0) return rc;
+  }
   int blocks = B < 4096 ? B : 4096;
   if (dtype == MADIFF_BF16)
     hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)qkv, ldq,
@@ -166,4 +180,262 @@ extern "C" int madiff_attn_bwd(int dtype, const void* qkv, int ldq, const void* 
                        (const float*)dout, ldd, (float*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual);
   MADIFF_CHECK_LAUNCH();
   return 0;
+}
+
+// ================================================================================================
+// v2: one workgroup per (batch element, head), 16-byte accesses, q/k head slices staged in LDS as fp32.
+// Used when A <= 8, d_qk and d_v are multiples of one vector and 2*A*T*d_qk floats fit in LDS; the generic
+// kernels above remain the fallback.
+// ================================================================================================
+template <typename T> struct AVec;
+template <> struct AVec<bf16_t> { static constexpr int E = 8; };
+template <> struct AVec<float>  { static constexpr int E = 4; };
+template <typename T> __device__ __forceinline__ void ald(const T* p, float (&f)[AVec<T>::E]);
+template <> __device__ __forceinline__ void ald<bf16_t>(const bf16_t* p, float (&f)[8]) {
+  bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; i++) f[i] = (float)v[i];
+}
+template <> __device__ __forceinline__ void ald<float>(const float* p, float (&f)[4]) {
+  f32x4 v = *(const f32x4*)p;
+#pragma unroll
+  for (int i = 0; i < 4; i++) f[i] = v[i];
+}
+template <typename T> __device__ __forceinline__ void ast(T* p, const float (&f)[AVec<T>::E]);
+template <> __device__ __forceinline__ void ast<bf16_t>(bf16_t* p, const float (&f)[8]) {
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = (bf16_t)f[i];
+  *(bf16x8*)p = v;
+}
+template <> __device__ __forceinline__ void ast<float>(float* p, const float (&f)[4]) {
+  *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]};
+}
+
+#define ATT2_AMAX 8
+
+// stage q and k head slices: qs[a][t*dqk + d], ks likewise; then P = softmax_a2(q.k * scale) in Ps[a1*A + a2]
+template <typename T>
+__device__ __forceinline__ void att2_scores(const T* __restrict__ qkv, int ldq, int b, int h, int A, int Tn, int dqk,
+                                            int Cq, float scale, float* qs, float* ks, float* Ps) {
+  constexpr int E = AVec<T>::E;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = Tn * dqk, vpr = dqk / E, nv = A * Tn * vpr;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    int cv = i % vpr, r = i / vpr, t = r % Tn, a = r / Tn;
+    const T* src = qkv + ((size_t)(b * A + a) * Tn + t) * ldq + h * dqk + cv * E;
+    float q[E], k[E];
+    ald<T>(src, q);
+    ald<T>(src + Cq, k);
+#pragma unroll
+    for (int e = 0; e < E; e++) { qs[a * L + t * dqk + cv * E + e] = q[e]; ks[a * L + t * dqk + cv * E + e] = k[e]; }
+  }
+  __syncthreads();
+  for (int e = wave; e < A * A; e += 4) {
+    int a1 = e / A, a2 = e - a1 * A;
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) s += qs[a1 * L + i] * ks[a2 * L + i];
+    s = wave_sum(s);
+    if (lane == 0) Ps[e] = s * scale;
+  }
+  __syncthreads();
+  if (threadIdx.x < A) {
+    float* p = Ps + threadIdx.x * A;
+    float mx = p[0];
+    for (int j = 1; j < A; j++) mx = fmaxf(mx, p[j]);
+    float sum = 0.f;
+    for (int j = 0; j < A; j++) { float ex = __expf(p[j] - mx); p[j] = ex; sum += ex; }
+    float inv = 1.f / sum;
+    for (int j = 0; j < A; j++) p[j] *= inv;
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_v2_kernel(const T* __restrict__ qkv, int ldq, const T* __restrict__ x, int ldx,
+                                                          T* __restrict__ out, int ldo, const float* __restrict__ gamma_p,
+                                                          int B, int A, int Tn, int H, int Cq, int C, float scale, int residual) {
+  constexpr int E = AVec<T>::E;
+  extern __shared__ float sm[];
+  const int dqk = Cq / H, dv = C / H, L = Tn * dqk;
+  float* qs = sm;
+  float* ks = sm + A * L;
+  float* Ps = ks + A * L;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const float gamma = residual ? gamma_p[0] : 1.f;
+  att2_scores<T>(qkv, ldq, b, h, A, Tn, dqk, Cq, scale, qs, ks, Ps);
+  const int vpr = dv / E, nv = Tn * vpr;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    int cv = i % vpr, t = i / vpr;
+    const int c = h * dv + cv * E;
+    float v[ATT2_AMAX][E];
+#pragma unroll
+    for (int a2 = 0; a2 < ATT2_AMAX; a2++)
+      if (a2 < A) ald<T>(qkv + ((size_t)(b * A + a2) * Tn + t) * ldq + 2 * Cq + c, v[a2]);
+#pragma unroll
+    for (int a1 = 0; a1 < ATT2_AMAX; a1++) {
+      if (a1 >= A) break;
+      float o[E];
+#pragma unroll
+      for (int e = 0; e < E; e++) o[e] = 0.f;
+#pragma unroll
+      for (int a2 = 0; a2 < ATT2_AMAX; a2++)
+        if (a2 < A) {
+          float p = Ps[a1 * A + a2];
+#pragma unroll
+          for (int e = 0; e < E; e++) o[e] += p * v[a2][e];
+        }
+      size_t row = (size_t)(b * A + a1) * Tn + t;
+      if (residual) {
+        float xv[E];
+        ald<T>(x + row * ldx + c, xv);
+#pragma unroll
+        for (int e = 0; e < E; e++) o[e] = xv[e] + gamma * o[e];
+      }
+      ast<T>(out + row * ldo + c, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_v2_kernel(const T* __restrict__ qkv, int ldq, const T* __restrict__ dout, int ldd,
+                                                          T* __restrict__ dqkv, int ldg, const float* __restrict__ gamma_p,
+                                                          float* __restrict__ dgamma, int B, int A, int Tn, int H, int Cq, int C,
+                                                          float scale, int residual) {
+  constexpr int E = AVec<T>::E;
+  extern __shared__ float sm[];
+  __shared__ float Dw[4][ATT2_AMAX * ATT2_AMAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dqk = Cq / H, dv = C / H, L = Tn * dqk;
+  float* qs = sm;
+  float* ks = sm + A * L;
+  float* Ps = ks + A * L;
+  float* Ds = Ps + A * A;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const float gamma = residual ? gamma_p[0] : 1.f;
+  att2_scores<T>(qkv, ldq, b, h, A, Tn, dqk, Cq, scale, qs, ks, Ps);
+  // pass over the value slice: raw dP[a1][a2] = sum dO[a1].v[a2] (per-thread partials) and dv = gamma * P^T dO
+  float dp[ATT2_AMAX][ATT2_AMAX];
+#pragma unroll
+  for (int i = 0; i < ATT2_AMAX; i++)
+#pragma unroll
+    for (int j = 0; j < ATT2_AMAX; j++) dp[i][j] = 0.f;
+  const int vprv = dv / E, nvv = Tn * vprv;
+  for (int i = threadIdx.x; i < nvv; i += 256) {
+    int cv = i % vprv, t = i / vprv;
+    const int c = h * dv + cv * E;
+    float v[ATT2_AMAX][E], g[ATT2_AMAX][E];
+#pragma unroll
+    for (int a = 0; a < ATT2_AMAX; a++)
+      if (a < A) {
+        size_t row = (size_t)(b * A + a) * Tn + t;
+        ald<T>(qkv + row * ldq + 2 * Cq + c, v[a]);
+        ald<T>(dout + row * ldd + c, g[a]);
+      }
+#pragma unroll
+    for (int a1 = 0; a1 < ATT2_AMAX; a1++)
+#pragma unroll
+      for (int a2 = 0; a2 < ATT2_AMAX; a2++)
+        if (a1 < A && a2 < A) {
+          float s = 0.f;
+#pragma unroll
+          for (int e = 0; e < E; e++) s += g[a1][e] * v[a2][e];
+          dp[a1][a2] += s;
+        }
+#pragma unroll
+    for (int a2 = 0; a2 < ATT2_AMAX; a2++) {
+      if (a2 >= A) break;
+      float o[E];
+#pragma unroll
+      for (int e = 0; e < E; e++) o[e] = 0.f;
+#pragma unroll
+      for (int a1 = 0; a1 < ATT2_AMAX; a1++)
+        if (a1 < A) {
+          float p = Ps[a1 * A + a2];
+#pragma unroll
+          for (int e = 0; e < E; e++) o[e] += p * g[a1][e];
+        }
+#pragma unroll
+      for (int e = 0; e < E; e++) o[e] *= gamma;
+      ast<T>(dqkv + ((size_t)(b * A + a2) * Tn + t) * ldg + 2 * Cq + c, o);
+    }
+  }
+#pragma unroll
+  for (int a1 = 0; a1 < ATT2_AMAX; a1++)
+#pragma unroll
+    for (int a2 = 0; a2 < ATT2_AMAX; a2++)
+      if (a1 < A && a2 < A) {
+        float s = wave_sum(dp[a1][a2]);
+        if (lane == 0) Dw[wave][a1 * A + a2] = s;
+      }
+  __syncthreads();
+  if (threadIdx.x < A) {       // row a1: dgamma partial and softmax backward -> dS (already times scale)
+    const int a1 = threadIdx.x;
+    float d[ATT2_AMAX], dot = 0.f;
+    for (int j = 0; j < A; j++) {
+      d[j] = Dw[0][a1 * A + j] + Dw[1][a1 * A + j] + Dw[2][a1 * A + j] + Dw[3][a1 * A + j];
+      dot += Ps[a1 * A + j] * d[j];
+    }
+    for (int j = 0; j < A; j++) Ds[a1 * A + j] = Ps[a1 * A + j] * gamma * (d[j] - dot) * scale;
+    Dw[0][a1] = dot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && residual) {
+    float dg = 0.f;
+    for (int a1 = 0; a1 < A; a1++) dg += Dw[0][a1];
+    atomicAdd(dgamma, dg);
+  }
+  // dq[a1] = sum_a2 dS[a1][a2] k[a2];  dk[a2] = sum_a1 dS[a1][a2] q[a1]   (q, k from LDS)
+  const int vpr = dqk / E, nv = A * Tn * vpr;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    int cv = i % vpr, r = i / vpr, t = r % Tn, a = r / Tn;
+    float oq[E], ok[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) { oq[e] = 0.f; ok[e] = 0.f; }
+    for (int o = 0; o < A; o++) {
+      float sq = Ds[a * A + o], sk = Ds[o * A + a];
+      const float* kk = ks + o * L + t * dqk + cv * E;
+      const float* qq = qs + o * L + t * dqk + cv * E;
+#pragma unroll
+      for (int e = 0; e < E; e++) { oq[e] += sq * kk[e]; ok[e] += sk * qq[e]; }
+    }
+    T* dst = dqkv + ((size_t)(b * A + a) * Tn + t) * ldg + h * dqk + cv * E;
+    ast<T>(dst, oq);
+    ast<T>(dst + Cq, ok);
+  }
+}
+
+static size_t att2_lds(int A, int T, int H, int Cq) { return ((size_t)2 * A * T * (Cq / H) + 2 * A * A) * sizeof(float); }
+
+static int att2_ok(int dtype, int A, int T, int H, int Cq, int C, int ld1, int ld2, int ld3) {
+  const int E = dtype == MADIFF_BF16 ? 8 : 4;
+  return A <= ATT2_AMAX && (Cq / H) % E == 0 && (C / H) % E == 0 && Cq % E == 0 && att2_lds(A, T, H, Cq) <= 60 * 1024 &&
+         ld1 % E == 0 && ld2 % E == 0 && ld3 % E == 0;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int madiff_attn_fwd_v2(int dtype, const void* qkv, int ldq, const void* x, int ldx,
+    void* out, int ldo, const float* gamma, int B, int A, int T, int H, int Cq, int C, float scale, int residual, hipStream_t stream) {
+  if (!att2_ok(dtype, A, T, H, Cq, C, ldq, ldx, ldo)) return 1;
+  size_t sh = att2_lds(A, T, H, Cq);
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((attn_fwd_v2_kernel<bf16_t>), dim3(B * H), dim3(256), sh, stream, (const bf16_t*)qkv, ldq, (const bf16_t*)x, ldx,
+                       (bf16_t*)out, ldo, gamma, B, A, T, H, Cq, C, scale, residual);
+  else
+    hipLaunchKernelGGL((attn_fwd_v2_kernel<float>), dim3(B * H), dim3(256), sh, stream, (const float*)qkv, ldq, (const float*)x, ldx,
+                       (float*)out, ldo, gamma, B, A, T, H, Cq, C, scale, residual);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int madiff_attn_bwd_v2(int dtype, const void* qkv, int ldq, const void* dout, int ldd,
+    void* dqkv, int ldg, const float* gamma, float* dgamma, int B, int A, int T, int H, int Cq, int C, float scale, int residual,
+    hipStream_t stream) {
+  if (!att2_ok(dtype, A, T, H, Cq, C, ldq, ldd, ldg)) return 1;
+  size_t sh = att2_lds(A, T, H, Cq);
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((attn_bwd_v2_kernel<bf16_t>), dim3(B * H), dim3(256), sh, stream, (const bf16_t*)qkv, ldq, (const bf16_t*)dout,
+                       ldd, (bf16_t*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual);
+  else
+    hipLaunchKernelGGL((attn_bwd_v2_kernel<float>), dim3(B * H), dim3(256), sh, stream, (const float*)qkv, ldq, (const float*)dout,
+                       ldd, (float*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }

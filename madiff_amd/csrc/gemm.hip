@@ -15,6 +15,7 @@
 // register prefetch + double buffering; the conv taps are realised as shifted row gathers while
 // staging, so no im2col matrix ever exists in memory.
 #include "common.h"
+#include <stdlib.h>
 
 struct RowMap {
   int T_out, T_in, stride, pad, tr;
@@ -352,20 +353,32 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict_
 }
 
 __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ grad, int O, int I, int Ipad,
-                                    int taps, long so, long si, long st) {
+                                    int taps, long so, long si, long st, int accumulate) {
   long total = (long)O * I * taps;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     int tap = e % taps;
     long r = e / taps;
     int i = r % I;
     long o = r / I;
-    grad[o * so + i * si + tap * st] = packed[(o * taps + tap) * Ipad + i];
+    float v = packed[(o * taps + tap) * Ipad + i];
+    float* dst = &grad[o * so + i * si + tap * st];
+    *dst = accumulate ? *dst + v : v;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+extern "C" int madiff_launch_gemm_fwd_bf16(const void* params, int out_f32, int grid_x, int grid_y, hipStream_t stream);
+extern "C" int madiff_launch_gemm_wgrad_bf16(const void* params, int gx, int gy, int gz, hipStream_t stream);
+
+// MADIFF_GEMM_IMPL=0 forces the generic register-staged kernel for bf16 too (A/B timing, debugging)
+static int use_dma_kernel() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MADIFF_GEMM_IMPL"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+
 static int check_rowmap(int T_out, int T_in, int stride, int pad, int tr) {
   return (T_out > 0 && T_in > 0 && stride > 0 && pad >= 0 && (tr == 0 || tr == 1)) ? 0 : -1;
 }
@@ -390,6 +403,8 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Npad; p.bias = bias; p.rowbias = rowbias; p.ldrb = ldrb;
   p.C = C; p.ldc = ldc; p.act = act; p.permT = permT; p.permA = permA;
   dim3 grid((M + 127) / 128, (Npad + 127) / 128), block(256);
+  if (dtype == MADIFF_BF16 && Cin % 64 == 0 && Csplit % 64 == 0 && use_dma_kernel())
+    return madiff_launch_gemm_fwd_bf16(&p, out_f32, grid.x, grid.y, stream);
   if (dtype == MADIFF_BF16) {
     if (out_f32) hipLaunchKernelGGL((gemm_fwd_kernel<bf16_t, float>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, stream, p);
@@ -415,10 +430,15 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
   p.M = M; p.Cin = Cin; p.taps = taps; p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.dW = dW; p.ldw = ldw; p.Nout = Nout;
   p.ctiles = (Cin + 127) / 128;
-  const int KR = dtype == MADIFF_BF16 ? 32 : 16;
+  const bool dma = dtype == MADIFF_BF16 && use_dma_kernel() && T_out < 256 && M < (1 << 24);
+  const int KR = dma ? 64 : (dtype == MADIFF_BF16 ? 32 : 16);
   int total_steps = (M + KR - 1) / KR;
   int tiles = ((Nout + 127) / 128) * p.ctiles * taps;
-  int splits = (1024 + tiles - 1) / tiles;              // aim at ~1024 workgroups
+  // every extra split costs one more fp32 atomic pass over dW (atomics run at ~1.3 TB/s chip-wide), so only split
+  // the reduction as far as needed to put ~2 workgroups on each of the 256 CUs
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("MADIFF_WGRAD_BLOCKS"); target = e ? atoi(e) : 384; }
+  int splits = (target + tiles / 2) / tiles;
   if (splits > total_steps / 4) splits = total_steps / 4 > 0 ? total_steps / 4 : 1;
   if (splits < 1) splits = 1;
   p.steps_per_split = (total_steps + splits - 1) / splits;
@@ -428,6 +448,7 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
     if (e != hipSuccess) return (int)e;
   }
   dim3 grid((Nout + 127) / 128, p.ctiles * taps, p.splits), block(256);
+  if (dma) return madiff_launch_gemm_wgrad_bf16(&p, grid.x, grid.y, grid.z, stream);
   if (dtype == MADIFF_BF16) hipLaunchKernelGGL((gemm_wgrad_kernel<bf16_t>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((gemm_wgrad_kernel<float>), grid, block, 0, stream, p);
   MADIFF_CHECK_LAUNCH();
@@ -448,11 +469,11 @@ extern "C" int madiff_pack_weight(int dtype, const float* src, void* dst, int O,
 }
 
 extern "C" int madiff_unpack_wgrad(const float* packed, float* grad, int O, int I, int Ipad, int taps, long so, long si,
-                                   long st, hipStream_t stream) {
+                                   long st, int accumulate, hipStream_t stream) {
   if (O <= 0 || I <= 0 || Ipad < I || taps <= 0) return -1;
   long total = (long)O * I * taps;
   int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, packed, grad, O, I, Ipad, taps, so, si, st);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, packed, grad, O, I, Ipad, taps, so, si, st, accumulate);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

@@ -70,13 +70,13 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(
     const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd, T* __restrict__ dy, int ldg,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ drowbias, int ldrb, int N, int Tn, int C, int Cpad, int G) {
-  extern __shared__ float lds[];   // [4 waves][3][Cg]: dgamma, dbeta, per-sequence d_rowbias
+    float* __restrict__ dbias, float* __restrict__ drowbias, int ldrb, int N, int Tn, int C, int Cpad, int G) {
+  extern __shared__ float lds[];   // [4 waves][4][Cg]: dgamma, dbeta, dbias (= sum dy), per-sequence d_rowbias
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Cg = C / G, E = Tn * Cg;
   const int g = blockIdx.x;
-  float* my = lds + wave * 3 * Cg;
-  for (int c = lane; c < 3 * Cg; c += 64) my[c] = 0.f;
+  float* my = lds + wave * 4 * Cg;
+  for (int c = lane; c < 4 * Cg; c += 64) my[c] = 0.f;
   __syncthreads();
   for (int n = blockIdx.y * 4 + wave; n < N; n += gridDim.y * 4) {
     const size_t rbase = (size_t)n * Tn;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(
         float dz = go * mish_grad_f(z);
         atomicAdd(&my[cl], dz * x);
         atomicAdd(&my[Cg + cl], dz);
-        if (drowbias) atomicAdd(&my[2 * Cg + cl], go);
+        if (drowbias) atomicAdd(&my[3 * Cg + cl], go);
         xh[i] = x;
         dxh[i] = dz * gm;
         s1 += dxh[i];
@@ -109,8 +109,10 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(
     for (int i = 0; i < GN_MAXE; i++) {
       int e = lane + 64 * i;
       if (e < E) {
-        int t = e / Cg, c = g * Cg + (e - t * Cg);
-        dy[(rbase + t) * ldg + c] = from_f32<T>(rstd * (dxh[i] - s1 - xh[i] * s2));
+        int t = e / Cg, cl = e - t * Cg, c = g * Cg + cl;
+        float d = rstd * (dxh[i] - s1 - xh[i] * s2);
+        dy[(rbase + t) * ldg + c] = from_f32<T>(d);
+        if (dbias) atomicAdd(&my[2 * Cg + cl], d);
       }
     }
     if (g == G - 1 && Cpad > C) {
@@ -122,17 +124,253 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(
     if (drowbias) {   // d temb[n, c] = sum_t dout: owned by this wave, plain store, then reset
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS atomics of this wave are done
       for (int c = lane; c < Cg; c += 64) {
-        drowbias[(size_t)n * ldrb + g * Cg + c] = my[2 * Cg + c];
-        my[2 * Cg + c] = 0.f;
+        drowbias[(size_t)n * ldrb + g * Cg + c] = my[3 * Cg + c];
+        my[3 * Cg + c] = 0.f;
       }
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * Cg; c += 256) {
-    float a = lds[c] + lds[3 * Cg + c] + lds[6 * Cg + c] + lds[9 * Cg + c];
-    if (c < Cg) atomicAdd(&dgamma[g * Cg + c], a);
-    else atomicAdd(&dbeta[g * Cg + c - Cg], a);
+  for (int c = threadIdx.x; c < 3 * Cg; c += 256) {
+    float a = lds[c] + lds[4 * Cg + c] + lds[8 * Cg + c] + lds[12 * Cg + c];
+    int q = c / Cg;
+    float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : dbias);
+    if (dst) atomicAdd(&dst[g * Cg + c - q * Cg], a);
   }
+}
+
+// ================================================================================================
+// Vectorised fast path (16-byte accesses): used when a group's channels are a multiple of one vector and the
+// vectors-per-row count is a power of two <= 64, i.e. every layer of the real model (Cg = 16, 64, 128).
+// One wave owns a (sequence, group) slab: <= VMAX vectors per lane, everything in registers.
+// Backward: a workgroup owns one group and strides over sequences; per-channel sums (dgamma, dbeta and the conv
+// bias gradient sum_m dy) stay in registers across all its sequences and are reduced once at the end.
+// ================================================================================================
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> { static constexpr int E = 8; };
+template <> struct Vec<float>  { static constexpr int E = 4; };
+
+template <typename T> __device__ __forceinline__ void load_vec(const T* p, float (&f)[Vec<T>::E]);
+template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, float (&f)[8]) {
+  bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; i++) f[i] = (float)v[i];
+}
+template <> __device__ __forceinline__ void load_vec<float>(const float* p, float (&f)[4]) {
+  f32x4 v = *(const f32x4*)p;
+#pragma unroll
+  for (int i = 0; i < 4; i++) f[i] = v[i];
+}
+template <typename T> __device__ __forceinline__ void store_vec(T* p, const float (&f)[Vec<T>::E]);
+template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const float (&f)[8]) {
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = (bf16_t)f[i];
+  *(bf16x8*)p = v;
+}
+template <> __device__ __forceinline__ void store_vec<float>(float* p, const float (&f)[4]) {
+  *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]};
+}
+
+#define GN_VMAX 4
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_mish_fwd_vec_kernel(
+    const T* __restrict__ y, int ldy, T* __restrict__ out, int ldo, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mean_out, float* __restrict__ rstd_out, int N, int Tn, int C,
+    int G, float eps, int mode, const float* __restrict__ rowbias, int ldrb, const T* __restrict__ res, int ldr,
+    int vpr_log2) {
+  constexpr int E = Vec<T>::E;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Cg = C / G, VPR = 1 << vpr_log2, NV = Tn * VPR;
+  const float inv_e = 1.f / (float)(Tn * Cg);
+  const long slabs = (long)N * G;
+  for (long s = (long)blockIdx.x * 4 + wave; s < slabs; s += (long)gridDim.x * 4) {
+    const int n = (int)(s / G), g = (int)(s - (long)n * G);
+    const size_t rbase = (size_t)n * Tn;
+    const int cv = lane & (VPR - 1);
+    const int c0 = g * Cg + cv * E;
+    float v[GN_VMAX][E];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_VMAX; i++) {
+      int vi = lane + 64 * i;
+      if (vi < NV) {
+        load_vec<T>(y + (rbase + (vi >> vpr_log2)) * ldy + c0, v[i]);
+#pragma unroll
+        for (int e = 0; e < E; e++) sum += v[i][e];
+      }
+    }
+    const float mean = wave_sum(sum) * inv_e;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_VMAX; i++)
+      if (lane + 64 * i < NV) {
+#pragma unroll
+        for (int e = 0; e < E; e++) { float d = v[i][e] - mean; sq += d * d; }
+      }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_e + eps);
+    if (lane == 0 && mean_out) { mean_out[s] = mean; rstd_out[s] = rstd; }
+    float gm[E], bt[E], rb[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      gm[e] = gamma[c0 + e];
+      bt[e] = beta[c0 + e];
+      rb[e] = mode == 1 ? rowbias[(size_t)n * ldrb + c0 + e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < GN_VMAX; i++) {
+      int vi = lane + 64 * i;
+      if (vi < NV) {
+        const size_t row = rbase + (vi >> vpr_log2);
+        float o[E];
+        if (mode == 2) load_vec<T>(res + row * ldr + c0, o);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          float z = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+          o[e] = mish_f(z) + (mode == 2 ? o[e] : rb[e]);
+        }
+        store_vec<T>(out + row * ldo + c0, o);
+      }
+    }
+  }
+}
+
+// grid = (G, NB).  Per-channel accumulators: lane owns channels c0..c0+E-1 for all its sequences.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_mish_bwd_vec_kernel(
+    const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd, T* __restrict__ dy, int ldg,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dbias, float* __restrict__ drowbias, int ldrb, int N, int Tn, int C, int G, int vpr_log2) {
+  constexpr int E = Vec<T>::E;
+  __shared__ float red[4][3][128 * 2];     // [wave][dgamma|dbeta|dbias][channels of one group] (Cg <= 256)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Cg = C / G, VPR = 1 << vpr_log2, NV = Tn * VPR;
+  const float inv_e = 1.f / (float)(Tn * Cg);
+  const int g = blockIdx.x;
+  const int cv = lane & (VPR - 1);
+  const int c0 = g * Cg + cv * E;
+  float gm[E], bt[E], a_dg[E], a_db[E], a_dbias[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) { gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; a_dg[e] = a_db[e] = a_dbias[e] = 0.f; }
+  for (int n = blockIdx.y * 4 + wave; n < N; n += gridDim.y * 4) {
+    const size_t rbase = (size_t)n * Tn;
+    const float mean = mean_in[(size_t)n * G + g], rstd = rstd_in[(size_t)n * G + g];
+    float xh[GN_VMAX][E], dxh[GN_VMAX][E], rbs[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) rbs[e] = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_VMAX; i++) {
+      int vi = lane + 64 * i;
+      if (vi < NV) {
+        const size_t row = rbase + (vi >> vpr_log2);
+        float yv[E], go[E];
+        load_vec<T>(y + row * ldy + c0, yv);
+        load_vec<T>(dout + row * ldd + c0, go);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          float x = (yv[e] - mean) * rstd;
+          float z = x * gm[e] + bt[e];
+          float dz = go[e] * mish_grad_f(z);
+          a_dg[e] += dz * x;
+          a_db[e] += dz;
+          rbs[e] += go[e];
+          xh[i][e] = x;
+          dxh[i][e] = dz * gm[e];
+          s1 += dxh[i][e];
+          s2 += dxh[i][e] * x;
+        }
+      }
+    }
+    s1 = wave_sum(s1) * inv_e;
+    s2 = wave_sum(s2) * inv_e;
+#pragma unroll
+    for (int i = 0; i < GN_VMAX; i++) {
+      int vi = lane + 64 * i;
+      if (vi < NV) {
+        const size_t row = rbase + (vi >> vpr_log2);
+        float o[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          o[e] = rstd * (dxh[i][e] - s1 - xh[i][e] * s2);
+          a_dbias[e] += o[e];
+        }
+        store_vec<T>(dy + row * ldg + c0, o);
+      }
+    }
+    if (drowbias) {   // d temb[n, c] = sum_t dout: reduce over the lanes that share this channel vector
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        float r = rbs[e];
+        for (int o = VPR; o < 64; o <<= 1) r += __shfl_xor(r, o, 64);
+        rbs[e] = r;
+      }
+      if (lane < VPR) {
+#pragma unroll
+        for (int e = 0; e < E; e++) drowbias[(size_t)n * ldrb + c0 + e] = rbs[e];
+      }
+    }
+  }
+  // per-channel reduction: lanes sharing cv, then the 4 waves, then one atomic per channel per workgroup
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    float a = a_dg[e], b = a_db[e], c = a_dbias[e];
+    for (int o = VPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+    if (lane < VPR) { red[wave][0][cv * E + e] = a; red[wave][1][cv * E + e] = b; red[wave][2][cv * E + e] = c; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * Cg; i += 256) {
+    int q = i / Cg, c = i - q * Cg;
+    float a = red[0][q][c] + red[1][q][c] + red[2][q][c] + red[3][q][c];
+    float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : dbias);
+    if (dst) atomicAdd(&dst[g * Cg + c], a);
+  }
+}
+
+static int vec_path(int dtype, int T, int C, int Cpad, int G, int* vpr_log2) {
+  const int E = dtype == MADIFF_BF16 ? 8 : 4;
+  const int Cg = C / G;
+  if (Cpad != C || Cg % E || Cg > 256) return 0;
+  int vpr = Cg / E;
+  if (vpr & (vpr - 1) || vpr > 64 || T * vpr > 64 * GN_VMAX) return 0;
+  int l = 0;
+  while ((1 << l) < vpr) l++;
+  *vpr_log2 = l;
+  return 1;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int madiff_gn_fwd_vec(int dtype, const void* y, int ldy, void* out, int ldo,
+    const float* gamma, const float* beta, float* mean, float* rstd, int N, int T, int C, int Cpad, int G, float eps, int mode,
+    const float* rowbias, int ldrb, const void* res, int ldr, hipStream_t stream) {
+  int l;
+  if (!vec_path(dtype, T, C, Cpad, G, &l) || ldy % 8 || ldo % 8 || (mode == 2 && ldr % 8)) return 1;
+  long slabs = (long)N * G;
+  int blocks = (int)((slabs + 3) / 4 < 16384 ? (slabs + 3) / 4 : 16384);
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((gn_mish_fwd_vec_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)y, ldy, (bf16_t*)out,
+                       ldo, gamma, beta, mean, rstd, N, T, C, G, eps, mode, rowbias, ldrb, (const bf16_t*)res, ldr, l);
+  else
+    hipLaunchKernelGGL((gn_mish_fwd_vec_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)y, ldy, (float*)out,
+                       ldo, gamma, beta, mean, rstd, N, T, C, G, eps, mode, rowbias, ldrb, (const float*)res, ldr, l);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int madiff_gn_bwd_vec(int dtype, const void* y, int ldy, const void* dout, int ldd,
+    void* dy, int ldg, const float* gamma, const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+    float* dbias, float* drowbias, int ldrb, int N, int T, int C, int Cpad, int G, hipStream_t stream) {
+  int l;
+  if (!vec_path(dtype, T, C, Cpad, G, &l) || ldy % 8 || ldd % 8 || ldg % 8) return 1;
+  int nb = (N + 3) / 4;
+  if (nb > 64) nb = 64;
+  dim3 grid(G, nb);
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((gn_mish_bwd_vec_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)y, ldy, (const bf16_t*)dout, ldd,
+                       (bf16_t*)dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias, drowbias, ldrb, N, T, C, G, l);
+  else
+    hipLaunchKernelGGL((gn_mish_bwd_vec_kernel<float>), grid, dim3(256), 0, stream, (const float*)y, ldy, (const float*)dout, ldd,
+                       (float*)dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias, drowbias, ldrb, N, T, C, G, l);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 extern "C" int madiff_gn_mish_fwd(int dtype, const void* y, int ldy, void* out, int ldo, const float* gamma,
@@ -143,6 +381,11 @@ extern "C" int madiff_gn_mish_fwd(int dtype, const void* y, int ldy, void* out, 
   if (C <= 0 || G <= 0 || C % G || T <= 0 || (long)T * (C / G) > 64 * GN_MAXE || Cpad < C || ldy < C || ldo < Cpad ||
       (mode == 1 && (!rowbias || ldrb < C)) || (mode == 2 && (!res || ldr < C)) || mode < 0 || mode > 2)
     return -1;
+  {
+    int rc = madiff_gn_fwd_vec(dtype, y, ldy, out, ldo, gamma, beta, mean, rstd, N, T, C, Cpad, G, eps, mode, rowbias, ldrb,
+                               res, ldr, stream);
+    if (rc <= 0) return rc;      // 0 = launched, <0 = error, 1 = shape not covered by the vector path
+  }
   long slabs = (long)N * G;
   int blocks = (int)((slabs + 3) / 4 < 8192 ? (slabs + 3) / 4 : 8192);
   if (dtype == MADIFF_BF16)
@@ -157,27 +400,34 @@ extern "C" int madiff_gn_mish_fwd(int dtype, const void* y, int ldy, void* out, 
   return 0;
 }
 
-// dgamma / dbeta must be zeroed by the caller (they are accumulated with atomics).
+// dgamma / dbeta / dbias ([C], dbias may be null = gradient of the bias of the conv feeding this norm, sum_m dy) are
+// ACCUMULATED with atomics: the caller zeroes them or passes live gradient buffers.
 extern "C" int madiff_gn_mish_bwd(int dtype, const void* y, int ldy, const void* dout, int ldd, void* dy, int ldg,
                                   const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                  float* dgamma, float* dbeta, float* drowbias, int ldrb, int N, int T, int C,
-                                  int Cpad, int G, hipStream_t stream) {
+                                  float* dgamma, float* dbeta, float* dbias, float* drowbias, int ldrb, int N,
+                                  int T, int C, int Cpad, int G, hipStream_t stream) {
   if (N <= 0) return 0;
   if (C <= 0 || G <= 0 || C % G || T <= 0 || (long)T * (C / G) > 64 * GN_MAXE || Cpad < C || ldy < C || ldd < C ||
       ldg < Cpad || (drowbias && ldrb < C))
     return -1;
+  {
+    int rc = madiff_gn_bwd_vec(dtype, y, ldy, dout, ldd, dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias, drowbias,
+                               ldrb, N, T, C, Cpad, G, stream);
+    if (rc <= 0) return rc;
+  }
   int nb = (N + 3) / 4;
   if (nb > 128) nb = 128;
-  size_t shmem = (size_t)4 * 3 * (C / G) * sizeof(float);
+  size_t shmem = (size_t)4 * 4 * (C / G) * sizeof(float);
   dim3 grid(G, nb);
   if (dtype == MADIFF_BF16)
     hipLaunchKernelGGL((gn_mish_bwd_kernel<bf16_t>), grid, dim3(256), shmem, stream, (const bf16_t*)y, ldy,
-                       (const bf16_t*)dout, ldd, (bf16_t*)dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, drowbias,
-                       ldrb, N, T, C, Cpad, G);
+                       (const bf16_t*)dout, ldd, (bf16_t*)dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias,
+                       drowbias, ldrb, N, T, C, Cpad, G);
   else
     hipLaunchKernelGGL((gn_mish_bwd_kernel<float>), grid, dim3(256), shmem, stream, (const float*)y, ldy,
-                       (const float*)dout, ldd, (float*)dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, drowbias,
-                       ldrb, N, T, C, Cpad, G);
+                       (const float*)dout, ldd, (float*)dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias,
+                       drowbias, ldrb, N, T, C, Cpad, G);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }
+

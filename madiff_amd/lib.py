@@ -22,9 +22,9 @@ _SIGS = {
                         _vp, _i, _i, _i, _i, _vp],
     "madiff_gemm_wgrad": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "madiff_pack_weight": [_i, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
-    "madiff_unpack_wgrad": [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _vp],
+    "madiff_unpack_wgrad": [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _i, _vp],
     "madiff_gn_mish_fwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _i, _vp],
-    "madiff_gn_mish_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "madiff_gn_mish_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_attn_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_attn_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_pack_input": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

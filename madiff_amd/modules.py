@@ -127,8 +127,8 @@ class Conv1dBlock(nn.Module):
 
     def forward_cl(self, x, t, x2=None, rowbias=None, res=None):
         conv, gn = self.block[0], self.block[2]
-        y = conv_gemm(x, [conv.weight], [conv.bias], self.spec, t, x2=x2)
-        return GNMish.apply(y, gn.weight, gn.bias, rowbias, res, y.shape[0] // t, t, self.out_channels, self.n_groups)
+        return ops.conv_block(x, conv.weight, conv.bias, gn.weight, gn.bias, self.spec, t, self.n_groups, x2=x2,
+                              rowbias=rowbias, res=res)
 
     def forward(self, x):
         n, _, t = x.shape

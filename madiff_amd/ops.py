@@ -222,6 +222,150 @@ def unpack_traj(xcl: torch.Tensor, B, T, A, F) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------
+# gradient sinks: let backward kernels accumulate straight into the optimizer's flat gradient buffer
+# ------------------------------------------------------------------------------------------------
+class GradSink:
+    """Maps a parameter to a live fp32 gradient view (same shape, contiguous).  When installed (ops.SINK), the
+    backward kernels ACCUMULATE parameter gradients into these views and return None to autograd, which removes
+    one temporary, one zero-fill and one `grad += new` pass per parameter.  `notify(param)` is called after the
+    write (the data-parallel optimizer counts bucket readiness there)."""
+
+    def __init__(self):
+        self.views = {}
+        self.notify = None
+
+    def register(self, param, view):
+        assert view.dtype == torch.float32 and view.is_contiguous() and view.shape == param.shape
+        self.views[id(param)] = (weakref.ref(param), view)
+
+    def get(self, param):
+        ent = self.views.get(id(param))
+        if ent is None or ent[0]() is not param:
+            return None
+        return ent[1]
+
+    def done(self, param):
+        if self.notify is not None:
+            self.notify(param)
+
+
+SINK: Optional[GradSink] = None
+
+
+def _sink_view(param):
+    return None if SINK is None else SINK.get(param)
+
+
+class _Geom:
+    pass
+
+
+def _conv_forward(x, x2, rowbias, spec: ConvSpec, t_in: int, act: int, perm, weights, biases):
+    _chk_cl(x)
+    dims = [_strides(spec.kind, w) for w in weights]
+    I = dims[0][1]
+    osum = sum(d[0] for d in dims)
+    c1 = x.shape[1]
+    cin = c1 + (x2.shape[1] if x2 is not None else 0)
+    assert cin == pad32(I) or (x2 is not None and cin == I), (cin, I)
+    M_in = x.shape[0]
+    n_seq = M_in // t_in
+    t_out = spec.out_len(t_in)
+    M = n_seq * t_out
+    W = _packed(weights, spec, False)
+    if len(biases) == 0:
+        bias = None
+    elif len(biases) == 1:
+        bias = biases[0]
+    else:
+        bias = torch.cat([b.detach() for b in biases])
+    out_f32 = perm == "f32"
+    if out_f32:
+        perm = None
+        npad = pad32(osum)
+        out = torch.empty(M, npad, dtype=torch.float32, device=x.device)
+    elif perm is not None:
+        out = torch.empty(M, osum, dtype=torch.float32, device=x.device)
+        npad = osum
+    else:
+        npad = pad32(osum)
+        out = torch.empty(M, npad, dtype=act_dtype(), device=x.device)
+    if x2 is not None:
+        _chk_cl(x2)
+    g = _Geom()
+    # algorithmic FLOPs of this layer = 2 * dense MACs (the count SURVEY.md section 8d uses); the data- and
+    # weight-gradient launches of the same layer do the same number of MACs
+    g.flops = 2.0 * (M_in if spec.tr else M) * osum * I * spec.taps
+    _timed("gemm_fwd_kernel", g.flops,
+           lambda: _gemm(x, x2, c1, M, cin, spec, t_out, t_in, spec.tr, W, osum, npad, bias, rowbias, out, act, perm))
+    g.spec, g.t_in, g.t_out, g.act, g.perm = spec, t_in, t_out, act, perm
+    g.dims, g.osum, g.cin, g.c1, g.n_seq, g.I = dims, osum, cin, c1, n_seq, I
+    return out, g
+
+
+def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bias_mode, need_rb):
+    """dy: cl [M_out, pad32(osum)] in the storage dtype.  bias_mode: 'colsum' | 'none' (bias gradient produced
+    elsewhere, e.g. by the fused GroupNorm backward).  Returns (dx, dx2, drowbias, [gw], [gb])."""
+    spec, t_in, t_out, osum, cin, c1, n_seq, I = g.spec, g.t_in, g.t_out, g.osum, g.cin, g.c1, g.n_seq, g.I
+    M, M_in, npad = n_seq * t_out, n_seq * t_in, pad32(osum)
+    dx = dx2 = drb = None
+    if need_dx or (x2 is not None and need_dx2):
+        Wb = _packed(weights, spec, True)          # [I, taps * npad]
+        es = Wb.element_size()
+        parts = [(0, c1 if x2 is not None else I, need_dx)]
+        if x2 is not None:
+            parts.append((c1, I - c1, need_dx2))
+        grads = []
+        for (row0, rows, need) in parts:
+            if not need:
+                grads.append(None)
+                continue
+            gx = torch.empty(M_in, pad32(rows), dtype=act_dtype(), device=dy.device)
+            _timed("gemm_fwd_kernel", g.flops * rows / I, lambda: lib.call(
+                "madiff_gemm_fwd", _dt(), 0, dy.data_ptr(), dy.stride(0), None, 0, npad, M_in, npad, spec.taps,
+                t_in, t_out, spec.stride, spec.pad, 1 - spec.tr, Wb.data_ptr() + row0 * Wb.stride(0) * es,
+                Wb.stride(0), rows, pad32(rows), None, None, 0, gx.data_ptr(), gx.stride(0), 0, 0, 0, _stream()))
+            grads.append(gx)
+        dx = grads[0]
+        if x2 is not None:
+            dx2 = grads[1]
+    gw: List[Optional[torch.Tensor]] = [None] * len(weights)
+    if any(need_w):
+        dW = torch.empty(osum, spec.taps * cin, dtype=torch.float32, device=dy.device)
+        _timed("gemm_wgrad_kernel", g.flops, lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum))
+        off = 0
+        for i, (w, (O, I_, so, si, st)) in enumerate(zip(weights, g.dims)):
+            if need_w[i]:
+                view = _sink_view(w)
+                dst = view if view is not None else torch.empty_like(w)
+                lib.call("madiff_unpack_wgrad", dW.data_ptr() + off * dW.stride(0) * 4, dst.data_ptr(), O, I_, cin,
+                         spec.taps, so, si, st, int(view is not None), _stream())
+                if view is None:
+                    gw[i] = dst
+                else:
+                    SINK.done(w)
+            off += O
+    gb: List[Optional[torch.Tensor]] = [None] * len(biases)
+    if biases and bias_mode == "colsum":
+        if len(biases) == 1 and _sink_view(biases[0]) is not None:
+            view = _sink_view(biases[0])       # colsum accumulates atomically: add straight into the live gradient
+            lib.call("madiff_colsum", _dt(), dy.data_ptr(), dy.stride(0), view.data_ptr(), M, osum, _stream())
+            SINK.done(biases[0])
+        else:
+            db = torch.zeros(osum, dtype=torch.float32, device=dy.device)
+            lib.call("madiff_colsum", _dt(), dy.data_ptr(), dy.stride(0), db.data_ptr(), M, osum, _stream())
+            off = 0
+            for i, (O, *_r) in enumerate(g.dims):
+                gb[i] = db[off:off + O]
+                off += O
+    if need_rb:
+        drb = torch.empty(n_seq, osum, dtype=torch.float32, device=dy.device)
+        lib.call("madiff_seqsum", _dt(), dy.data_ptr(), dy.stride(0), drb.data_ptr(), drb.stride(0), n_seq, t_out,
+                 osum, _stream())
+    return dx, dx2, drb, gw, gb
+
+
 class ConvGemm(torch.autograd.Function):
     """y = conv/linear(x [, x2]) + bias (+ rowbias[n]) for a GROUP of layers sharing the input.
 
@@ -232,117 +376,33 @@ class ConvGemm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, rowbias, spec: ConvSpec, t_in: int, act: int, perm, n_groups: int, *params):
         weights, biases = params[:n_groups], params[n_groups:]
-        _chk_cl(x)
-        dims = [_strides(spec.kind, w) for w in weights]
-        I = dims[0][1]
-        osum = sum(d[0] for d in dims)
-        c1 = x.shape[1]
-        cin = c1 + (x2.shape[1] if x2 is not None else 0)
-        assert cin == pad32(I) or (x2 is not None and cin == I), (cin, I)
-        M_in = x.shape[0]
-        n_seq = M_in // t_in
-        t_out = spec.out_len(t_in)
-        M = n_seq * t_out
-        W = _packed(weights, spec, False)
-        if len(biases) == 0:
-            bias = None
-        elif len(biases) == 1:
-            bias = biases[0]
-        else:
-            bias = torch.cat([b.detach() for b in biases])
-        out_f32 = perm == "f32"
-        if out_f32:
-            perm = None
-            npad = pad32(osum)
-            out = torch.empty(M, npad, dtype=torch.float32, device=x.device)
-        elif perm is not None:
-            out = torch.empty(M, osum, dtype=torch.float32, device=x.device)
-            npad = osum
-        else:
-            npad = pad32(osum)
-            out = torch.empty(M, npad, dtype=act_dtype(), device=x.device)
-        if x2 is not None:
-            _chk_cl(x2)
-        # algorithmic FLOPs of this layer = 2 * dense MACs (the count SURVEY.md section 8d uses); the data- and
-        # weight-gradient launches of the same layer do the same number of MACs
-        ctx.flops = flops = 2.0 * (M_in if spec.tr else M) * osum * I * spec.taps
-        _timed("gemm_fwd_kernel", flops,
-               lambda: _gemm(x, x2, c1, M, cin, spec, t_out, t_in, spec.tr, W, osum, npad, bias, rowbias, out, act, perm))
-        ctx.save_for_backward(x, x2, out if act == 1 else None, *weights)
-        ctx.spec, ctx.t_in, ctx.t_out, ctx.act, ctx.perm = spec, t_in, t_out, act, perm
-        ctx.n_groups, ctx.has_bias, ctx.has_rowbias = n_groups, len(biases) > 0, rowbias is not None
-        ctx.dims, ctx.osum, ctx.cin, ctx.c1, ctx.n_seq = dims, osum, cin, c1, n_seq
+        out, g = _conv_forward(x, x2, rowbias, spec, t_in, act, perm, weights, biases)
+        ctx.save_for_backward(x, x2, out if act == 1 else None, *params)
+        ctx.g, ctx.n_groups, ctx.has_rowbias = g, n_groups, rowbias is not None
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, x2, y_act = ctx.saved_tensors[:3]
-        weights = ctx.saved_tensors[3:]
-        spec, t_in, t_out, osum, cin, c1, n_seq = ctx.spec, ctx.t_in, ctx.t_out, ctx.osum, ctx.cin, ctx.c1, ctx.n_seq
-        M = n_seq * t_out
-        M_in = n_seq * t_in
-        npad = pad32(osum)
-        if ctx.perm is not None:       # dy arrives as fp32 [B*T*A, O] in the reference row order
-            Tn, A = ctx.perm
-            dy = pack_traj(dy.reshape(n_seq // A, Tn, A, osum), npad)
+        params = ctx.saved_tensors[3:]
+        g, ng = ctx.g, ctx.n_groups
+        weights, biases = params[:ng], params[ng:]
+        npad = pad32(g.osum)
+        if g.perm is not None:       # dy arrives as fp32 [B*T*A, O] in the reference row order
+            Tn, A = g.perm
+            dy = pack_traj(dy.reshape(g.n_seq // A, Tn, A, g.osum), npad)
         else:
             dy = dy.contiguous()
             if dy.dtype != act_dtype():
                 dy = dy.to(act_dtype())
-        if ctx.act == 1:
+        if g.act == 1:
             d2 = torch.empty_like(dy)
             lib.call("madiff_act_bwd", _dt(), 1, y_act.data_ptr(), dy.data_ptr(), d2.data_ptr(), dy.numel(), _stream())
             dy = d2
         needs = ctx.needs_input_grad
-        dx = dx2 = drb = None
-        I = ctx.dims[0][1]
-        # data gradient(s): the same kernel with the tap direction flipped
-        if needs[0] or (x2 is not None and needs[1]):
-            Wb = _packed(weights, spec, True)          # [I, taps * npad]
-            es = Wb.element_size()
-            parts = [(0, c1 if x2 is not None else I, needs[0])]
-            if x2 is not None:
-                parts.append((c1, I - c1, needs[1]))
-            grads = []
-            for (row0, rows, need) in parts:
-                if not need:
-                    grads.append(None)
-                    continue
-                g = torch.empty(M_in, pad32(rows), dtype=act_dtype(), device=dy.device)
-                _timed("gemm_fwd_kernel", ctx.flops * rows / I, lambda: lib.call(
-                    "madiff_gemm_fwd", _dt(), 0, dy.data_ptr(), dy.stride(0), None, 0, npad, M_in, npad, spec.taps,
-                    t_in, t_out, spec.stride, spec.pad, 1 - spec.tr, Wb.data_ptr() + row0 * Wb.stride(0) * es,
-                    Wb.stride(0), rows, pad32(rows), None, None, 0, g.data_ptr(), g.stride(0), 0, 0, 0, _stream()))
-                grads.append(g)
-            dx = grads[0]
-            if x2 is not None:
-                dx2 = grads[1]
-        # weight gradient (fp32, GEMM layout) -> parameter layout
-        gw: List[Optional[torch.Tensor]] = [None] * ctx.n_groups
-        if any(needs[8 + i] for i in range(ctx.n_groups)):
-            ipad = cin if x2 is None else cin   # K of the forward GEMM (already padded, or exact for a split input)
-            dW = torch.empty(osum, spec.taps * ipad, dtype=torch.float32, device=dy.device)
-            _timed("gemm_wgrad_kernel", ctx.flops, lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum))
-            off = 0
-            for i, (w, (O, I_, so, si, st)) in enumerate(zip(weights, ctx.dims)):
-                if needs[8 + i]:
-                    g = torch.empty_like(w)
-                    lib.call("madiff_unpack_wgrad", dW.data_ptr() + off * dW.stride(0) * 4, g.data_ptr(), O, I_, ipad,
-                             spec.taps, so, si, st, _stream())
-                    gw[i] = g
-                off += O
-        gb: List[Optional[torch.Tensor]] = []
-        if ctx.has_bias:
-            db = torch.zeros(osum, dtype=torch.float32, device=dy.device)
-            lib.call("madiff_colsum", _dt(), dy.data_ptr(), dy.stride(0), db.data_ptr(), M, osum, _stream())
-            off = 0
-            for (O, *_r) in ctx.dims:
-                gb.append(db[off:off + O])
-                off += O
-        if ctx.has_rowbias and needs[2]:
-            drb = torch.empty(n_seq, osum, dtype=torch.float32, device=dy.device)
-            lib.call("madiff_seqsum", _dt(), dy.data_ptr(), dy.stride(0), drb.data_ptr(), drb.stride(0), n_seq, t_out,
-                     osum, _stream())
+        dx, dx2, drb, gw, gb = _conv_backward(g, x, x2, weights, biases, dy, needs[0], needs[1],
+                                              [needs[8 + i] for i in range(ng)], "colsum",
+                                              ctx.has_rowbias and needs[2])
         return (dx, dx2, drb, None, None, None, None, None, *gw, *gb)
 
 
@@ -354,40 +414,94 @@ def conv_gemm(x, weights, biases, spec: ConvSpec, t_in: int, x2=None, rowbias=No
     return ConvGemm.apply(x, x2, rowbias, spec, t_in, act, perm, len(weights), *weights, *biases)
 
 
+def _gn_forward(y, gamma, beta, rowbias, res, n_seq, t, C, G):
+    _chk_cl(y)
+    cpad = y.shape[1]
+    out = torch.empty_like(y)
+    stats = torch.empty(2, n_seq * G, dtype=torch.float32, device=y.device)
+    mode = 1 if rowbias is not None else (2 if res is not None else 0)
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.stride(1) == 1
+    if res is not None:
+        _chk_cl(res)
+    lib.call("madiff_gn_mish_fwd", _dt(), y.data_ptr(), y.stride(0), out.data_ptr(), out.stride(0), gamma.data_ptr(),
+             beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), n_seq, t, C, cpad, G, 1e-5, mode, _p(rowbias),
+             0 if rowbias is None else rowbias.stride(0), _p(res), 0 if res is None else res.stride(0), _stream())
+    return out, stats, (n_seq, t, C, cpad, G, mode)
+
+
+def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None):
+    """-> (dy, dgamma, dbeta, dconv_bias, drowbias); parameter gradients go to the sink when one is installed."""
+    n_seq, t, C, cpad, G, mode = geom
+    dout = dout.contiguous()
+    dy = torch.empty_like(y)
+    plist = [gamma, beta] + ([conv_bias] if conv_bias is not None else [])
+    views = [_sink_view(p_) for p_ in plist]
+    tmp = None
+    if any(v is None for v in views):
+        tmp = torch.zeros(len(plist), C, dtype=torch.float32, device=y.device)
+    bufs = [v if v is not None else tmp[i] for i, v in enumerate(views)]
+    drb = torch.empty(n_seq, C, dtype=torch.float32, device=y.device) if mode == 1 else None
+    lib.call("madiff_gn_mish_bwd", _dt(), y.data_ptr(), y.stride(0), dout.data_ptr(), dout.stride(0), dy.data_ptr(),
+             dy.stride(0), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+             bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr() if conv_bias is not None else None, _p(drb), C,
+             n_seq, t, C, cpad, G, _stream())
+    outs = []
+    for p_, v, b in zip(plist, views, bufs):
+        if v is not None:
+            SINK.done(p_)
+            outs.append(None)
+        else:
+            outs.append(b)
+    if conv_bias is None:
+        outs.append(None)
+    return dy, outs[0], outs[1], outs[2], drb, dout
+
+
+class ConvBlock(torch.autograd.Function):
+    """Conv1dBlock as ONE autograd node: implicit-GEMM conv -> GroupNorm -> Mish (+ rowbias | + residual).
+    Backward: fused GN/Mish backward (which also yields the conv-bias gradient), then data + weight gradient GEMMs.
+
+    apply(x, x2, rowbias, res, spec, t_in, G, w, b, gamma, beta)"""
+
+    @staticmethod
+    def forward(ctx, x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w, b, gamma, beta):
+        y, g = _conv_forward(x, x2, None, spec, t_in, 0, None, [w], [b])
+        out, stats, geom = _gn_forward(y, gamma, beta, rowbias, res, g.n_seq, g.t_out, g.osum, G)
+        ctx.save_for_backward(x, x2, y, stats, w, b, gamma, beta)
+        ctx.g, ctx.geom = g, geom
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, x2, y, stats, w, b, gamma, beta = ctx.saved_tensors
+        needs = ctx.needs_input_grad
+        dy, dgamma, dbeta, dbias, drb, dres = _gn_backward(y, gamma, beta, stats, ctx.geom, dout, conv_bias=b)
+        dx, dx2, _, gw, _ = _conv_backward(ctx.g, x, x2, [w], [b], dy, needs[0], needs[1], [needs[7]], "none", False)
+        return (dx, dx2, drb, dres if ctx.geom[5] == 2 else None, None, None, None, gw[0], dbias, dgamma, dbeta)
+
+
+def conv_block(x, w, b, gamma, beta, spec: ConvSpec, t_in: int, G: int, x2=None, rowbias=None, res=None):
+    if x2 is not None and x.shape[1] % 128 != 0:
+        x, x2 = torch.cat((x, x2), dim=1), None
+    return ConvBlock.apply(x, x2, rowbias, res, spec, t_in, G, w, b, gamma, beta)
+
+
 class GNMish(torch.autograd.Function):
     """GroupNorm(8) + Mish (+ rowbias[n] | + residual) on a cl tensor."""
 
     @staticmethod
     def forward(ctx, y, gamma, beta, rowbias, res, n_seq: int, t: int, C: int, G: int):
-        _chk_cl(y)
-        cpad = y.shape[1]
-        out = torch.empty_like(y)
-        mean = torch.empty(n_seq * G, dtype=torch.float32, device=y.device)
-        rstd = torch.empty_like(mean)
-        mode = 1 if rowbias is not None else (2 if res is not None else 0)
-        if rowbias is not None:
-            assert rowbias.dtype == torch.float32 and rowbias.stride(1) == 1
-        if res is not None:
-            _chk_cl(res)
-        lib.call("madiff_gn_mish_fwd", _dt(), y.data_ptr(), y.stride(0), out.data_ptr(), out.stride(0), gamma.data_ptr(),
-                 beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n_seq, t, C, cpad, G, 1e-5, mode, _p(rowbias),
-                 0 if rowbias is None else rowbias.stride(0), _p(res), 0 if res is None else res.stride(0), _stream())
-        ctx.save_for_backward(y, gamma, beta, mean, rstd)
-        ctx.geom = (n_seq, t, C, cpad, G, mode)
+        out, stats, geom = _gn_forward(y, gamma, beta, rowbias, res, n_seq, t, C, G)
+        ctx.save_for_backward(y, gamma, beta, stats)
+        ctx.geom = geom
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, gamma, beta, mean, rstd = ctx.saved_tensors
-        n_seq, t, C, cpad, G, mode = ctx.geom
-        dout = dout.contiguous()
-        dy = torch.empty_like(y)
-        dgb = torch.zeros(2, C, dtype=torch.float32, device=y.device)
-        drb = torch.empty(n_seq, C, dtype=torch.float32, device=y.device) if mode == 1 else None
-        lib.call("madiff_gn_mish_bwd", _dt(), y.data_ptr(), y.stride(0), dout.data_ptr(), dout.stride(0), dy.data_ptr(),
-                 dy.stride(0), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dgb[0].data_ptr(),
-                 dgb[1].data_ptr(), _p(drb), C, n_seq, t, C, cpad, G, _stream())
-        return dy, dgb[0], dgb[1], drb, (dout if mode == 2 else None), None, None, None, None
+        y, gamma, beta, stats = ctx.saved_tensors
+        dy, dgamma, dbeta, _, drb, dres = _gn_backward(y, gamma, beta, stats, ctx.geom, dout)
+        return dy, dgamma, dbeta, drb, (dres if ctx.geom[5] == 2 else None), None, None, None, None
 
 
 class AttnCore(torch.autograd.Function):
@@ -414,9 +528,13 @@ class AttnCore(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         if dqkv.shape[1] > 2 * Cq + C:
             dqkv[:, 2 * Cq + C:].zero_()
-        dgamma = torch.zeros(1, dtype=torch.float32, device=qkv.device) if residual else None
+        view = _sink_view(gamma) if residual else None
+        dgamma = view if view is not None else (torch.zeros(1, dtype=torch.float32, device=qkv.device) if residual else None)
         lib.call("madiff_attn_bwd", _dt(), qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0),
                  dqkv.data_ptr(), dqkv.stride(0), _p(gamma), _p(dgamma), B, A, T, H, Cq, C, int(residual), _stream())
+        if view is not None:
+            SINK.done(gamma)
+            dgamma = None
         return dqkv, (dout if residual else None), dgamma, None, None, None, None, None, None, None
 
 

@@ -96,11 +96,21 @@ class FlatAdamEMA:
         for b in self.buckets:
             for i in b["members"]:
                 self._bucket_of[i] = b
+        self._index = {id(p): i for i, p in enumerate(self.params)}
         if self.world > 1:
             if dev.type == "cuda":
                 self._comm_stream = torch.cuda.Stream(device=dev)
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        if self.use_hip:
+            # backward kernels accumulate parameter gradients straight into the flat buffer (ops.GradSink)
+            sink = ops.GradSink()
+            for p, o in zip(self.params, offs):
+                sink.register(p, self.flat_g[o:o + p.numel()].view_as(p))
+            if self.world > 1:
+                hooks = [self._make_hook(i) for i in range(len(self.params))]
+                sink.notify = lambda p: hooks[self._index[id(p)]](p)
+            ops.SINK = sink
 
     def _make_hook(self, i):
         def hook(_p):

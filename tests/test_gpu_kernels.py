@@ -266,3 +266,55 @@ def test_adam_ema_kernel():
                  torch.cuda.current_stream().cuda_stream)
     assert rel_err(p.cpu(), ref_p.detach().cpu()) < 1e-6
     assert rel_err(ema.cpu(), ema_ref.cpu()) < 1e-6
+
+
+def test_flat_optimizer_with_gradient_sink_matches_torch_adam():
+    """FlatAdamEMA (flat buffers + fused Adam/EMA kernel + backward kernels accumulating straight into the flat
+    gradient through ops.GradSink) against torch.optim.Adam + the reference's EMA rule on a twin model."""
+    import copy
+    import diffuser.models as DM
+    from madiff_amd import ops
+    from madiff_amd.host import batch_to_device
+    from madiff_amd.trainer import FlatAdamEMA, train_step
+    from oracle import madiff_oracle as O
+    dev = _dev()
+    ops.set_precision("fp32")
+    try:
+        torch.manual_seed(0)
+        A, T, Fd = 3, 24, 18
+        net = DM.SharedConvAttentionDeconv(horizon=T, transition_dim=Fd, dim=32, dim_mults=(1, 4, 8), n_agents=A,
+                                           returns_condition=True, condition_dropout=0.25)
+        dif = DM.GaussianDiffusion(net, n_agents=A, horizon=T, history_horizon=0, observation_dim=Fd, action_dim=5,
+                                   n_timesteps=50, returns_condition=True, hidden_dim=64).to(dev)
+        for a in net.self_attn:
+            a.gamma.data.fill_(0.3)
+        twin = copy.deepcopy(dif)
+        ema, ema_twin = copy.deepcopy(dif), copy.deepcopy(dif)
+        opt = FlatAdamEMA(dif, ema, lr=1e-3, ema_decay=0.9)
+        topt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+        batches = [batch_to_device(O.synthetic_batch(4, T, A, Fd, 5, 0, seed=s), dev) for s in range(4)]
+        g = torch.Generator().manual_seed(5)
+        for step in range(2):
+            draws = []
+            for i in range(2):
+                draws.append(dict(t=torch.randint(0, 50, (4,), generator=g).to(dev),
+                                  noise=torch.randn(4, T, A, Fd, generator=g).to(dev),
+                                  dropout_mask=torch.ones(4, A, 1, device=dev)))
+            mb = [{**batches[2 * step + i], **draws[i]} for i in range(2)]
+            train_step(dif, opt, mb, do_ema=1)
+            for b in mb:
+                loss, _ = twin.loss(**b)
+                (loss / 2).backward()
+            topt.step()
+            topt.zero_grad()
+            with torch.no_grad():
+                for pe, pt in zip(ema_twin.parameters(), twin.parameters()):
+                    pe.mul_(0.9).add_(pt, alpha=0.1)
+        assert ops.SINK is not None
+        for (k, p), (_, q) in zip(dif.named_parameters(), twin.named_parameters()):
+            assert rel_err(p.detach().cpu(), q.detach().cpu()) < 2e-4, k
+        for (k, p), (_, q) in zip(ema.named_parameters(), ema_twin.named_parameters()):
+            assert rel_err(p.detach().cpu(), q.detach().cpu()) < 2e-4, k
+    finally:
+        ops.SINK = None
+        ops.set_precision("bf16")
