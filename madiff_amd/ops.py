@@ -172,6 +172,15 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
+def _gemm_label(cin: int, csplit: int, out_f32: bool) -> str:
+    """Name of the kernel symbol madiff_gemm_fwd dispatches to (so bench.py's figures line up with rocprofv3's)."""
+    if _PRECISION != "bf16":
+        return "gemm_fwd_kernel<float,float>"
+    if cin % 64 == 0 and csplit % 64 == 0 and os.environ.get("MADIFF_GEMM_IMPL", "1") != "0":
+        return "gemm_fwd_bf16_kernel<float>" if out_f32 else "gemm_fwd_bf16_kernel<bf16>"
+    return "gemm_fwd_kernel<bf16,float>" if out_f32 else "gemm_fwd_kernel<bf16,bf16>"
+
+
 def _timed(name: str, flops: float, launch):
     if TIMER is None:
         launch()
@@ -297,7 +306,7 @@ def _conv_forward(x, x2, rowbias, spec: ConvSpec, t_in: int, act: int, perm, wei
     # algorithmic FLOPs of this layer = 2 * dense MACs (the count SURVEY.md section 8d uses); the data- and
     # weight-gradient launches of the same layer do the same number of MACs
     g.flops = 2.0 * (M_in if spec.tr else M) * osum * I * spec.taps
-    _timed("gemm_fwd_kernel", g.flops,
+    _timed(_gemm_label(cin, c1, out.dtype == torch.float32), g.flops,
            lambda: _gemm(x, x2, c1, M, cin, spec, t_out, t_in, spec.tr, W, osum, npad, bias, rowbias, out, act, perm))
     g.spec, g.t_in, g.t_out, g.act, g.perm = spec, t_in, t_out, act, perm
     g.dims, g.osum, g.cin, g.c1, g.n_seq, g.I = dims, osum, cin, c1, n_seq, I
@@ -322,7 +331,7 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
                 grads.append(None)
                 continue
             gx = torch.empty(M_in, pad32(rows), dtype=act_dtype(), device=dy.device)
-            _timed("gemm_fwd_kernel", g.flops * rows / I, lambda: lib.call(
+            _timed(_gemm_label(npad, npad, False), g.flops * rows / I, lambda: lib.call(
                 "madiff_gemm_fwd", _dt(), 0, dy.data_ptr(), dy.stride(0), None, 0, npad, M_in, npad, spec.taps,
                 t_in, t_out, spec.stride, spec.pad, 1 - spec.tr, Wb.data_ptr() + row0 * Wb.stride(0) * es,
                 Wb.stride(0), rows, pad32(rows), None, None, 0, gx.data_ptr(), gx.stride(0), 0, 0, 0, _stream()))
@@ -333,7 +342,8 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
     gw: List[Optional[torch.Tensor]] = [None] * len(weights)
     if any(need_w):
         dW = torch.empty(osum, spec.taps * cin, dtype=torch.float32, device=dy.device)
-        _timed("gemm_wgrad_kernel", g.flops, lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum))
+        _timed("gemm_wgrad_bf16_kernel" if _PRECISION == "bf16" else "gemm_wgrad_kernel<float>", g.flops,
+               lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum))
         off = 0
         for i, (w, (O, I_, so, si, st)) in enumerate(zip(weights, g.dims)):
             if need_w[i]:
