@@ -55,6 +55,9 @@ int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void*
  * pack writes dst[(o*taps + tap)*dst_ld + dst_off + i] and leaves pad columns alone (buffer is zero-filled once). */
 int madiff_pack_weight(int dtype, const float* src, void* dst, int O, int I, int taps, long so, long si, long st,
                        int dst_ld, int dst_off, madiff_stream_t stream);
+/* One launch for many pack jobs.  table (device): n_desc rows of 12 int64 {src, dst, O, I, taps, so, si, st, dst_ld,
+ * dst_off, n_elems = O*taps*I, first_block}; row r owns blocks [first_block_r, first_block_{r+1}), 2048 elements each. */
+int madiff_pack_weights_multi(int dtype, const long* table, int n_desc, int total_blocks, madiff_stream_t stream);
 int madiff_unpack_wgrad(const float* packed, float* grad, int O, int I, int Ipad, int taps, long so, long si, long st,
                         int accumulate, madiff_stream_t stream);
 
@@ -117,9 +120,11 @@ int madiff_colsum(int dtype, const void* x, int ld, float* out, long M, int C, m
 int madiff_seqsum(int dtype, const void* x, int ld, float* out, int ldo, long N, int T, int C, madiff_stream_t stream);
 
 /* Fused Adam (torch.optim.Adam defaults, diffuser/utils/training.py:109,154) + EMA (training.py:20-39) over one flat
- * fp32 tensor.  do_ema: 0 none, 1 lerp with ema_beta, 2 copy. */
+ * fp32 tensor.  do_ema: 0 none, 1 lerp with ema_beta, 2 copy.  state == NULL: bias corrections and do_ema come from the
+ * arguments; state != NULL (device int[2] = {completed steps, do_ema}): they are derived on the device and state[0] is
+ * incremented afterwards (hipGraph replay of a whole train step). */
 int madiff_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
-                    float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta,
+                    float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta, int* state,
                     madiff_stream_t stream);
 
 #ifdef __cplusplus

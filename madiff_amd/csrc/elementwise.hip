@@ -179,6 +179,42 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   __syncthreads();
   if (ry == 0 && c < C) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// vectorised colsum (ld and C multiples of the 16-byte vector): 32 column vectors x 8 rows per block
+template <typename T, int E>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, long M, int C) {
+  __shared__ float red[8][32 * E];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + tx) * E;
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) acc[e] = 0.f;
+  if (c0 < C) {
+    for (long m = (long)blockIdx.y * 8 + ty; m < M; m += (long)gridDim.y * 8) {
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 v = *(const bf16x8*)(x + m * ld + c0);
+#pragma unroll
+        for (int e = 0; e < E; e++) acc[e] += (float)v[e];
+      } else {
+        f32x4 v = *(const f32x4*)(x + m * ld + c0);
+#pragma unroll
+        for (int e = 0; e < E; e++) acc[e] += v[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) red[ty][tx * E + e] = acc[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * E; i += 256) {
+    int c = blockIdx.x * 32 * E + i;
+    if (c < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; r++) s += red[r][i];
+      atomicAdd(&out[c], s);
+    }
+  }
+}
+
 // seqsum: out[n, c] = sum_t x[(n, t), c]
 template <typename T>
 __global__ void seqsum_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, int ldo, long N, int Tn, int C) {
@@ -197,7 +233,14 @@ __global__ void seqsum_kernel(const T* __restrict__ x, int ld, float* __restrict
 // ema = beta*ema + (1-beta)*p when do_ema == 1, ema = p when do_ema == 2 (the "copy until step 2000" phase).
 __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, float* __restrict__ ema, long n, float lr, float b1, float b2,
-                                float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta) {
+                                float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta,
+                                const int* __restrict__ state) {
+  if (state) {   // device-resident step counter / EMA flag: one captured launch serves every step of a hipGraph
+    const double step = (double)(state[0] + 1);
+    bc1 = (float)(1.0 - pow((double)b1, step));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
+    do_ema = state[1];
+  }
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     float gr = g[e] * grad_scale;
     float mm = b1 * m[e] + (1.f - b1) * gr;
@@ -335,6 +378,21 @@ extern "C" int madiff_act_bwd(int dtype, int kind, const void* ref, const void* 
 extern "C" int madiff_colsum(int dtype, const void* x, int ld, float* out, long M, int C, hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;
   if (ld < C) return -1;
+  {
+    const int E = dtype == MADIFF_BF16 ? 8 : 4;
+    if (ld % E == 0 && C % E == 0) {
+      int rbv = (int)((M + 63) / 64);
+      if (rbv > 128) rbv = 128;
+      if (rbv < 1) rbv = 1;
+      dim3 g((C / E + 31) / 32, rbv);
+      if (dtype == MADIFF_BF16)
+        hipLaunchKernelGGL((colsum_vec_kernel<bf16_t, 8>), g, dim3(256), 0, stream, (const bf16_t*)x, ld, out, M, C);
+      else
+        hipLaunchKernelGGL((colsum_vec_kernel<float, 4>), g, dim3(256), 0, stream, (const float*)x, ld, out, M, C);
+      MADIFF_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   int rb = (int)((M + 255) / 256);
   if (rb > 64) rb = 64;
   if (rb < 1) rb = 1;
@@ -360,13 +418,19 @@ extern "C" int madiff_seqsum(int dtype, const void* x, int ld, float* out, int l
 
 extern "C" int madiff_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float b1,
                                float b2, float eps, float bc1, float bc2s, float grad_scale, int do_ema,
-                               float ema_beta, hipStream_t stream) {
-  // bc1 = 1 - b1^step, bc2s = sqrt(1 - b2^step): computed by the host in double, as torch.optim.Adam does
+                               float ema_beta, int* state, hipStream_t stream) {
+  // state == null: bc1 = 1 - b1^step, bc2s = sqrt(1 - b2^step) and do_ema come from the host (computed in double, as
+  // torch.optim.Adam does).  state != null (device int[2] = {completed steps, do_ema}): both are derived on the device
+  // and state[0] is incremented afterwards, so the launch pair can live inside a replayed hipGraph.
   if (n <= 0) return 0;
-  if (!p || !g || !m || !v || bc1 <= 0.f || bc2s <= 0.f || (do_ema && !ema)) return -1;
+  if (!p || !g || !m || !v || (!state && (bc1 <= 0.f || bc2s <= 0.f)) || ((do_ema || state) && !ema && do_ema)) return -1;
   hipLaunchKernelGGL(adam_ema_kernel, dim3(nblocks(n, 256, 8192)), dim3(256), 0, stream, p, g, m, v, ema, n, lr, b1, b2, eps,
-                     bc1, bc2s, grad_scale, do_ema, ema_beta);
+                     bc1, bc2s, grad_scale, do_ema, ema_beta, (const int*)state);
   MADIFF_CHECK_LAUNCH();
+  if (state) {
+    hipLaunchKernelGGL(sampler_advance_kernel, dim3(1), dim3(64), 0, stream, state);
+    MADIFF_CHECK_LAUNCH();
+  }
   return 0;
 }
 

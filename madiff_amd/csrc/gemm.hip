@@ -352,6 +352,35 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict_
   }
 }
 
+// Multi-tensor variant: ONE launch repacks every stale weight of the model (a train step would otherwise issue
+// ~140 tiny pack launches).  table: n_desc rows of 12 int64 {src, dst, O, I, taps, so, si, st, dst_ld, dst_off,
+// n_elems, first_block}; each block handles PACK_EPB consecutive elements of one descriptor.
+#define PACK_EPB 2048
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __restrict__ table, int n_desc) {
+  int lo = 0, hi = n_desc - 1;
+  const long b = blockIdx.x;
+  while (lo < hi) {                       // last descriptor whose first_block <= b
+    int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 12 + 11] <= b) lo = mid; else hi = mid - 1;
+  }
+  const long* d = table + lo * 12;
+  const float* src = (const float*)d[0];
+  T* dst = (T*)d[1];
+  const int I = (int)d[3], taps = (int)d[4];
+  const long so = d[5], si = d[6], st = d[7], dst_ld = d[8], dst_off = d[9], total = d[10];
+  const long e0 = (b - d[11]) * PACK_EPB;
+  for (int k = threadIdx.x; k < PACK_EPB; k += 256) {
+    long e = e0 + k;
+    if (e >= total) break;
+    int i = e % I;
+    long r = e / I;
+    int tap = r % taps;
+    long o = r / taps;
+    dst[(o * taps + tap) * dst_ld + dst_off + i] = from_f32<T>(src[o * so + i * si + tap * st]);
+  }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ grad, int O, int I, int Ipad,
                                     int taps, long so, long si, long st, int accumulate) {
   long total = (long)O * I * taps;
@@ -464,6 +493,17 @@ extern "C" int madiff_pack_weight(int dtype, const float* src, void* dst, int O,
     hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, O, I, taps, so, si, st, dst_ld, dst_off);
   else
     hipLaunchKernelGGL((pack_weight_kernel<float>), dim3(blocks), dim3(256), 0, stream, src, (float*)dst, O, I, taps, so, si, st, dst_ld, dst_off);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_pack_weights_multi(int dtype, const long* table, int n_desc, int total_blocks, hipStream_t stream) {
+  if (n_desc <= 0 || total_blocks <= 0) return 0;
+  if (!table) return -1;
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((pack_weight_multi_kernel<bf16_t>), dim3(total_blocks), dim3(256), 0, stream, table, n_desc);
+  else
+    hipLaunchKernelGGL((pack_weight_multi_kernel<float>), dim3(total_blocks), dim3(256), 0, stream, table, n_desc);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

@@ -22,6 +22,7 @@ _SIGS = {
                         _vp, _i, _i, _i, _i, _vp],
     "madiff_gemm_wgrad": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "madiff_pack_weight": [_i, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
+    "madiff_pack_weights_multi": [_i, _vp, _i, _i, _vp],
     "madiff_unpack_wgrad": [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _i, _vp],
     "madiff_gn_mish_fwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _i, _vp],
     "madiff_gn_mish_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -40,7 +41,7 @@ _SIGS = {
     "madiff_act_bwd": [_i, _i, _vp, _vp, _vp, _l, _vp],
     "madiff_colsum": [_i, _vp, _i, _vp, _l, _i, _vp],
     "madiff_seqsum": [_i, _vp, _i, _vp, _i, _l, _i, _i, _vp],
-    "madiff_adam_ema": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp],
+    "madiff_adam_ema": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp, _vp],
 }
 
 if not os.path.exists(LIB_PATH):

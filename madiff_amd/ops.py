@@ -108,41 +108,95 @@ def params_changed() -> None:
     _EPOCH += 1
 
 
+PACK_EPB = 2048          # elements per block of madiff_pack_weights_multi (csrc/gemm.hip)
+_MULTI = {"sig": None, "table": None, "n": 0, "blocks": 0}
+
+
+class _PackEntry:
+    __slots__ = ("vers", "buf", "refs", "jobs")
+
+
+def _entry_vers(weights):
+    return (_EPOCH,) + tuple((w._version, w.data_ptr()) for w in weights)
+
+
+def _pack_jobs(weights, spec: ConvSpec, backward: bool, buf):
+    """[(src_ptr, dst_ptr, O, I, taps, so, si, st, dst_ld, dst_off)] for one cache entry."""
+    dims = [_strides(spec.kind, w) for w in weights]
+    I = dims[0][1]
+    Osum = sum(d[0] for d in dims)
+    es = buf.element_size()
+    jobs, off = [], 0
+    for w, (O, I_, so, si, st) in zip(weights, dims):
+        assert I_ == I and w.dtype == torch.float32 and w.is_contiguous()
+        if backward:   # rows = i, cols = (tap, o): swap the roles of o and i
+            jobs.append((w.data_ptr(), buf.data_ptr(), I, O, spec.taps, si, so, st, pad32(Osum), off))
+        else:
+            jobs.append((w.data_ptr(), buf.data_ptr() + off * spec.taps * pad32(I) * es, O, I, spec.taps, so, si, st,
+                         pad32(I), 0))
+        off += O
+    return jobs
+
+
+def _refresh_stale(trigger_key):
+    """Repack every stale cache entry whose parameters are alive with ONE multi-tensor launch (train steps make
+    all ~150 entries stale at once).  Falls back to per-entry launches for a single stale entry."""
+    stale = []
+    for key, ent in list(_PACK_CACHE.items()):
+        ws = [r() for r in ent.refs]
+        if any(w is None for w in ws):
+            continue
+        v = _entry_vers(ws)
+        if v != ent.vers:
+            stale.append((key, ent, ws, v))
+    if not stale:
+        return
+    if len(stale) == 1:
+        key, ent, ws, v = stale[0]
+        for j in ent.jobs(ws):
+            lib.call("madiff_pack_weight", _dt(), j[0], j[1], j[2], j[3], j[4], j[5], j[6], j[7], j[8], j[9], _stream())
+        ent.vers = v
+        return
+    rows, blk = [], 0
+    for key, ent, ws, v in stale:
+        for j in ent.jobs(ws):
+            n = j[2] * j[3] * j[4]
+            rows.append(list(j) + [n, blk])
+            blk += (n + PACK_EPB - 1) // PACK_EPB
+    sig = tuple(tuple(r) for r in rows)
+    if _MULTI["sig"] != sig:
+        dev = stale[0][1].buf.device
+        _MULTI["table"] = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _MULTI["sig"], _MULTI["n"], _MULTI["blocks"] = sig, len(rows), blk
+    lib.call("madiff_pack_weights_multi", _dt(), _MULTI["table"].data_ptr(), _MULTI["n"], _MULTI["blocks"], _stream())
+    for key, ent, ws, v in stale:
+        ent.vers = v
+
+
 def _packed(weights: Sequence[torch.Tensor], spec: ConvSpec, backward: bool) -> torch.Tensor:
     """GEMM-layout copy of a group of parameters that share the input (concatenated along the output dim).
 
     forward : [sum O, taps * pad32(I)]        backward (data gradient): [I, taps * pad32(sum O)]
     """
     key = (tuple(id(w) for w in weights), spec.kind, spec.taps, backward, _PRECISION)
-    vers = (_EPOCH,) + tuple((w._version, w.data_ptr()) for w in weights)
     ent = _PACK_CACHE.get(key)
-    if ent is not None and not all(r() is w for r, w in zip(ent[2], weights)):
+    if ent is not None and not all(r() is w for r, w in zip(ent.refs, weights)):
         ent = None                      # id() of a dead parameter was reused by a new object
-    if ent is not None and ent[0] == vers:
-        return ent[1]
-    dims = [_strides(spec.kind, w) for w in weights]
-    I = dims[0][1]
-    Osum = sum(d[0] for d in dims)
     if ent is None:
+        dims = [_strides(spec.kind, w) for w in weights]
+        I = dims[0][1]
+        Osum = sum(d[0] for d in dims)
         shape = (I, spec.taps * pad32(Osum)) if backward else (Osum, spec.taps * pad32(I))
-        buf = torch.zeros(shape, dtype=act_dtype(), device=weights[0].device)
-    else:
-        buf = ent[1]
-    off = 0
-    es = buf.element_size()
-    for w, (O, I_, so, si, st) in zip(weights, dims):
-        assert I_ == I and w.dtype == torch.float32 and w.is_contiguous()
-        if backward:   # rows = i, cols = (tap, o): swap the roles of o and i
-            lib.call("madiff_pack_weight", _dt(), w.data_ptr(), buf.data_ptr(), I, O, spec.taps, si, so, st,
-                     pad32(Osum), off, _stream())
-        else:
-            lib.call("madiff_pack_weight", _dt(), w.data_ptr(), buf.data_ptr() + off * spec.taps * pad32(I) * es, O, I,
-                     spec.taps, so, si, st, pad32(I), 0, _stream())
-        off += O
-    refs = ent[2] if ent is not None else tuple(weakref.ref(w, lambda _r, k=key: _PACK_CACHE.pop(k, None))
-                                                for w in weights)
-    _PACK_CACHE[key] = (vers, buf, refs)
-    return buf
+        ent = _PackEntry()
+        ent.buf = torch.zeros(shape, dtype=act_dtype(), device=weights[0].device)
+        ent.vers = None
+        ent.refs = tuple(weakref.ref(w, lambda _r, k=key: _PACK_CACHE.pop(k, None)) for w in weights)
+        buf = ent.buf
+        ent.jobs = lambda ws, spec=spec, backward=backward, buf=buf: _pack_jobs(ws, spec, backward, buf)
+        _PACK_CACHE[key] = ent
+    if ent.vers != _entry_vers(weights):
+        _refresh_stale(key)
+    return ent.buf
 
 
 def clear_pack_cache() -> None:

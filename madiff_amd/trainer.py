@@ -176,7 +176,7 @@ class FlatAdamEMA:
         if self.use_hip:
             lib.call("madiff_adam_ema", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                      self.flat_v.data_ptr(), None if self.flat_ema is None else self.flat_ema.data_ptr(), self.total,
-                     self.lr, b1, b2, self.eps, bc1, bc2s, scale, do_ema, self.ema_decay,
+                     self.lr, b1, b2, self.eps, bc1, bc2s, scale, do_ema, self.ema_decay, None,
                      torch.cuda.current_stream().cuda_stream)
             ops.params_changed()
         else:   # host arithmetic for the gloo/CPU tests of the data-parallel machinery only

@@ -6,9 +6,16 @@ from madiff_amd import ops
 ops.set_precision("bf16")
 dev = torch.device("cuda:0")
 N = 1024
-shapes = [("T2 1024->1024 k5", 6, 1024, 1024, ops.CONV5), ("T2 2048->512 k5", 6, 2048, 512, ops.CONV5),
-          ("T1 512->512 k5", 12, 512, 512, ops.CONV5), ("T0 128->128 k5", 24, 128, 128, ops.CONV5),
-          ("T2 1024->1536 1x1", 6, 1024, 1536, ops.CONV1), ("T1 1024->128 k5", 12, 1024, 128, ops.CONV5)]
+# (name, T, Cin, Cout, spec, count per forward)
+shapes = [("T2 1024->1024 k5", 6, 1024, 1024, ops.CONV5, 7), ("T2 2048->512 k5", 6, 2048, 512, ops.CONV5, 1),
+          ("T2 512->1024 k5", 6, 512, 1024, ops.CONV5, 1), ("T2 512->512 k5", 6, 512, 512, ops.CONV5, 3),
+          ("T1 512->512 k5", 12, 512, 512, ops.CONV5, 3), ("T1 128->512 k5", 12, 128, 512, ops.CONV5, 1),
+          ("T1 1024->128 k5", 12, 1024, 128, ops.CONV5, 1), ("T1 128->128 k5", 12, 128, 128, ops.CONV5, 3),
+          ("T0 128->128 k5", 24, 128, 128, ops.CONV5, 4),
+          ("T2 1024->1536 1x1", 6, 1024, 1536, ops.CONV1, 2), ("T1 512->768 1x1", 12, 512, 768, ops.CONV1, 1),
+          ("T2 512->1024 1x1", 6, 512, 1024, ops.CONV1, 1), ("T2 2048->512 1x1", 6, 2048, 512, ops.CONV1, 1),
+          ("T1 128->512 1x1", 12, 128, 512, ops.CONV1, 1), ("T1 1024->128 1x1", 12, 1024, 128, ops.CONV1, 1)]
+tot = [0.0, 0.0, 0.0]
 def timeit(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -17,7 +24,7 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for name, T, ci, co, spec in shapes:
+for name, T, ci, co, spec, cnt in shapes:
     x = torch.randn(N * T, ci, device=dev).to(torch.bfloat16).requires_grad_(True)
     w = (torch.randn(co, ci, spec.taps, device=dev) / (ci * spec.taps) ** 0.5).requires_grad_(True)
     b = torch.zeros(co, device=dev, requires_grad=True)
@@ -34,4 +41,6 @@ for name, T, ci, co, spec in shapes:
     td = timeit(dgrad)
     dW = torch.empty(co, spec.taps * ci, dtype=torch.float32, device=dev)
     tw = timeit(lambda: ops._wgrad(gy, x.detach(), None, ci, N * T, ci, spec, T, T, dW, co))
-    print(f"{name:22s} fwd {tf*1e3:7.1f} us {flops/tf/1e9:7.1f} TF | dgrad {td*1e3:7.1f} us {flops/td/1e9:7.1f} TF | wgrad {tw*1e3:7.1f} us {flops/tw/1e9:7.1f} TF", flush=True)
+    tot[0] += cnt * tf; tot[1] += cnt * td; tot[2] += cnt * tw
+    print(f"{name:22s} x{cnt} fwd {tf*1e3:7.1f} us {flops/tf/1e9:7.1f} TF | dgrad {td*1e3:7.1f} us {flops/td/1e9:7.1f} TF | wgrad {tw*1e3:7.1f} us {flops/tw/1e9:7.1f} TF", flush=True)
+print(f"weighted totals per step (ms): fwd {tot[0]:.3f} dgrad {tot[1]:.3f} wgrad {tot[2]:.3f}")

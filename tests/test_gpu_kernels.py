@@ -262,7 +262,7 @@ def test_adam_ema_kernel():
         ema_ref = 0.995 * ema_ref + 0.005 * ref_p.detach()
         gs = g * step
         lib.call("madiff_adam_ema", p.data_ptr(), gs.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(), n, 2e-4,
-                 0.9, 0.999, 1e-8, 1 - 0.9 ** step, math.sqrt(1 - 0.999 ** step), 1.0, 1, 0.995,
+                 0.9, 0.999, 1e-8, 1 - 0.9 ** step, math.sqrt(1 - 0.999 ** step), 1.0, 1, 0.995, None,
                  torch.cuda.current_stream().cuda_stream)
     assert rel_err(p.cpu(), ref_p.detach().cpu()) < 1e-6
     assert rel_err(ema.cpu(), ema_ref.cpu()) < 1e-6
