@@ -175,7 +175,7 @@ def main():
 
     if rank == 0:
         summ = timer.summary()
-        dom = "gemm_fwd_bf16_kernel<bf16>"
+        dom = "gemm_fwd_bf16_kernel"
         d = summ[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         kernels = {k: {"launches_per_step": v["launches"] / args.steps, "avg_us": 1e3 * v["ms"] / v["launches"],
@@ -191,7 +191,7 @@ def main():
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}",
                        "step": "loss fwd + bwd + bucketed all-reduce + fused Adam (+EMA every 10)"},
             "loss": float(loss),
-            "roofline": {"bound": "mfma", "kernel": "gemm_fwd_bf16_kernel<bf16> (LDS-DMA implicit-GEMM conv/linear, forward + data-gradient launches)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_fwd_bf16_kernel<OutT, BM, BN, WT> (LDS-DMA implicit-GEMM conv/linear: forward + data-gradient launches, all tile instantiations)",
                          "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TF,
                          "traffic": None, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                          "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,

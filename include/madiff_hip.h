@@ -39,17 +39,30 @@ const char* madiff_arch(void);
  * (helpers.py:32-47), the 1x1 residual / Q,K,V convs (models/temporal.py:70-72,183-187), every nn.Linear
  * (temporal.py:74-88,177-181,231-251; models/diffusion.py:111-119) and their data gradients.
  * act: 0 none, 1 relu, 2 mish.  permA > 0 stores rows (b, a, t) as (b, t, a) (the "b a f t -> b t a f" of
- * models/ma_temporal.py:416).  out_f32 != 0 writes fp32 output in the bf16 build. */
+ * models/ma_temporal.py:416).  out_f32 != 0 writes fp32 output in the bf16 build.
+ * tile: output tile of the gfx950 LDS-DMA kernel, 0..madiff_gemm_tile_count()-1 = {128x128, 96x128, 64x128, 128x64,
+ * 96x64, 64x64}; < 0 lets the library choose.  Results do not depend on the tile. */
 int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, const void* X2, int ldx2, int Csplit, int M, int Cin,
                     int taps, int T_out, int T_in, int stride, int pad, int tr, const void* W, int ldw, int Nout, int Npad,
                     const float* bias, const float* rowbias, int ldrb, void* C, int ldc, int act, int permT, int permA,
-                    madiff_stream_t stream);
+                    int tile, madiff_stream_t stream);
+int madiff_gemm_tile_count(void);
 
-/* Weight gradient of the above: dW[o, tap*Cin + c] = sum_m dY[m, o] * X[src(m, tap), c]  (fp32 output).
- * Replaces the wgrad half of autograd for the same modules. */
+/* Data gradient of the same modules (the dgrad half of autograd for nn.Conv1d / ConvTranspose1d / Linear) computed
+ * straight from the FORWARD bf16 weight matrix W [Kred rows = output channels, ldw = taps*wtap]:
+ *   dX[m, n] = sum_{tap, o} dY[src(m, tap), o] * W[o, tap*wtap + wcol0 + n],  n < Ncols (pad columns up to Npad are 0).
+ * bf16 only; returns 1 (nothing launched) when the shape is not covered (Kred % 64 != 0): the caller then runs
+ * madiff_gemm_fwd on a transposed weight pack.  tile: 0..2 = {128x128, 96x128, 64x128}, < 0 = library's choice. */
+int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, int taps, int T_out, int T_in, int stride, int pad,
+                         int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad, void* dX, int ldx,
+                         int tile, madiff_stream_t stream);
+
+/* Weight gradient of the above: dW[o, tap*Cin + c] (+)= sum_m dY[m, o] * X[src(m, tap), c]  (fp32 output).
+ * Replaces the wgrad half of autograd for the same modules.  accumulate != 0 adds into dW (a live gradient buffer
+ * kept in this GEMM layout by the flat optimizer), 0 overwrites. */
 int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,
                       int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,
-                      int ldw, int Nout, madiff_stream_t stream);
+                      int ldw, int Nout, int accumulate, madiff_stream_t stream);
 
 /* Parameter layout (fp32, element (o, i, tap) at o*so + i*si + tap*st) <-> GEMM layout [O, taps, Ipad].
  * pack writes dst[(o*taps + tap)*dst_ld + dst_off + i] and leaves pad columns alone (buffer is zero-filled once). */
@@ -58,8 +71,6 @@ int madiff_pack_weight(int dtype, const float* src, void* dst, int O, int I, int
 /* One launch for many pack jobs.  table (device): n_desc rows of 12 int64 {src, dst, O, I, taps, so, si, st, dst_ld,
  * dst_off, n_elems = O*taps*I, first_block}; row r owns blocks [first_block_r, first_block_{r+1}), 2048 elements each. */
 int madiff_pack_weights_multi(int dtype, const long* table, int n_desc, int total_blocks, madiff_stream_t stream);
-int madiff_unpack_wgrad(const float* packed, float* grad, int O, int I, int Ipad, int taps, long so, long si, long st,
-                        int accumulate, madiff_stream_t stream);
 
 /* Fused GroupNorm(G) + Mish + {mode 1: + rowbias[n, c] (timestep embedding), mode 2: + res[m, c] (residual)}.
  * Replaces helpers.py:67-71 plus the adds of temporal.py:197-200.  mean/rstd [N, G] are saved for backward. */
@@ -122,10 +133,12 @@ int madiff_seqsum(int dtype, const void* x, int ld, float* out, int ldo, long N,
 /* Fused Adam (torch.optim.Adam defaults, diffuser/utils/training.py:109,154) + EMA (training.py:20-39) over one flat
  * fp32 tensor.  do_ema: 0 none, 1 lerp with ema_beta, 2 copy.  state == NULL: bias corrections and do_ema come from the
  * arguments; state != NULL (device int[2] = {completed steps, do_ema}): they are derived on the device and state[0] is
- * incremented afterwards (hipGraph replay of a whole train step). */
-int madiff_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
+ * incremented afterwards (hipGraph replay of a whole train step).  shadow_bf16 != NULL: the bf16 rounding of every
+ * updated parameter is written to shadow_bf16[e] (the flat buffer is kept in GEMM layout, so that copy is the packed
+ * weight operand of the next step).  zero_grad != 0 clears g after it was consumed (optimizer.zero_grad, :155). */
+int madiff_adam_ema(float* p, float* g, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
                     float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta, int* state,
-                    madiff_stream_t stream);
+                    void* shadow_bf16, int zero_grad, madiff_stream_t stream);
 
 #ifdef __cplusplus
 }

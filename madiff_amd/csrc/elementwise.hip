@@ -231,10 +231,12 @@ __global__ void seqsum_kernel(const T* __restrict__ x, int ld, float* __restrict
 // ---------------------------------------------------------------- fused Adam + EMA over one flat tensor
 // torch.optim.Adam defaults (training.py:109): no weight decay, no amsgrad.  EMA (training.py:20-39):
 // ema = beta*ema + (1-beta)*p when do_ema == 1, ema = p when do_ema == 2 (the "copy until step 2000" phase).
-__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// shadow != null: the bf16 copy of the updated parameter is written alongside (the flat buffer is kept in GEMM layout,
+// so this IS the packed forward weight of the next step: no separate pack pass).  zero_grad: g is cleared after use.
+__global__ void adam_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, float* __restrict__ ema, long n, float lr, float b1, float b2,
                                 float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta,
-                                const int* __restrict__ state) {
+                                const int* __restrict__ state, bf16_t* __restrict__ shadow, int zero_grad) {
   if (state) {   // device-resident step counter / EMA flag: one captured launch serves every step of a hipGraph
     const double step = (double)(state[0] + 1);
     bc1 = (float)(1.0 - pow((double)b1, step));
@@ -243,6 +245,7 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
   }
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     float gr = g[e] * grad_scale;
+    if (zero_grad) g[e] = 0.f;
     float mm = b1 * m[e] + (1.f - b1) * gr;
     float vv = b2 * v[e] + (1.f - b2) * gr * gr;
     m[e] = mm;
@@ -250,6 +253,7 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
     float denom = sqrtf(vv) / bc2_sqrt + eps;
     float pv = p[e] - (lr / bc1) * (mm / denom);
     p[e] = pv;
+    if (shadow) shadow[e] = (bf16_t)pv;
     if (do_ema == 1) ema[e] = ema_beta * ema[e] + (1.f - ema_beta) * pv;
     else if (do_ema == 2) ema[e] = pv;
   }
@@ -416,16 +420,16 @@ extern "C" int madiff_seqsum(int dtype, const void* x, int ld, float* out, int l
   return 0;
 }
 
-extern "C" int madiff_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float b1,
+extern "C" int madiff_adam_ema(float* p, float* g, float* m, float* v, float* ema, long n, float lr, float b1,
                                float b2, float eps, float bc1, float bc2s, float grad_scale, int do_ema,
-                               float ema_beta, int* state, hipStream_t stream) {
+                               float ema_beta, int* state, void* shadow_bf16, int zero_grad, hipStream_t stream) {
   // state == null: bc1 = 1 - b1^step, bc2s = sqrt(1 - b2^step) and do_ema come from the host (computed in double, as
   // torch.optim.Adam does).  state != null (device int[2] = {completed steps, do_ema}): both are derived on the device
   // and state[0] is incremented afterwards, so the launch pair can live inside a replayed hipGraph.
   if (n <= 0) return 0;
   if (!p || !g || !m || !v || (!state && (bc1 <= 0.f || bc2s <= 0.f)) || ((do_ema || state) && !ema && do_ema)) return -1;
   hipLaunchKernelGGL(adam_ema_kernel, dim3(nblocks(n, 256, 8192)), dim3(256), 0, stream, p, g, m, v, ema, n, lr, b1, b2, eps,
-                     bc1, bc2s, grad_scale, do_ema, ema_beta, (const int*)state);
+                     bc1, bc2s, grad_scale, do_ema, ema_beta, (const int*)state, (bf16_t*)shadow_bf16, zero_grad);
   MADIFF_CHECK_LAUNCH();
   if (state) {
     hipLaunchKernelGGL(sampler_advance_kernel, dim3(1), dim3(64), 0, stream, state);

@@ -14,45 +14,12 @@
 // Tiles are 128x128 per 256-thread workgroup (4 waves, 64x64 each), operands staged through LDS with
 // register prefetch + double buffering; the conv taps are realised as shifted row gathers while
 // staging, so no im2col matrix ever exists in memory.
-#include "common.h"
+#include "gemm_params.h"
 #include <stdlib.h>
-
-struct RowMap {
-  int T_out, T_in, stride, pad, tr;
-};
-
-struct GemmFwdParams {
-  const void* X;   int ldx;          // first source  (channels [0, Csplit))
-  const void* X2;  int ldx2;         // second source (channels [Csplit, Cin)), may be null
-  int Csplit;                        // == Cin when X2 is null
-  int M, Cin, taps;                  // M output rows; Cin padded channel count (multiple of KC)
-  RowMap rm;
-  const void* W;   int ldw;          // [Nout, taps*Cin]
-  int Nout, Npad;                    // real / padded output columns (pad columns are written as 0)
-  const float* bias;                 // [Nout] or null
-  const float* rowbias; int ldrb;    // [n_seq, ldrb] or null, row = m / T_out
-  void* C;         int ldc;
-  int act;                           // 0 none, 1 relu, 2 mish
-  int permT, permA;                  // if permA > 0: rows (b, a, t) are stored as (b, t, a)
-};
 
 template <typename T> struct MfmaTraits;
 template <> struct MfmaTraits<bf16_t> { static constexpr int KC = 32; };
 template <> struct MfmaTraits<float>  { static constexpr int KC = 16; };
-
-__device__ __forceinline__ int map_row(int n, int t, int tap, const RowMap& rm) {
-  int ti;
-  if (!rm.tr) {
-    ti = t * rm.stride + tap - rm.pad;
-    if (ti < 0 || ti >= rm.T_in) return -1;
-  } else {
-    int num = t + rm.pad - tap;
-    if (num < 0) return -1;
-    ti = num / rm.stride;
-    if (ti * rm.stride != num || ti >= rm.T_in) return -1;
-  }
-  return n * rm.T_in + ti;
-}
 
 __device__ __forceinline__ void mma_step(const bf16x8 (&a)[4], const bf16x8 (&b)[4], f32x4 (&acc)[4][4]) {
 #pragma unroll
@@ -193,19 +160,6 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmFwdParams p) {
 // ------------------------------------------------------------------------------------------------
 // weight gradient: dW[o, tap*Cin + c] = sum_m dY[m, o] * X[src(m, tap), c]
 // ------------------------------------------------------------------------------------------------
-struct GemmWgradParams {
-  const void* dY;  int ldy;  int Ycols;   // Ycols: padded column count of dY (multiple of 32)
-  const void* X;   int ldx;
-  const void* X2;  int ldx2;
-  int Csplit;
-  int M, Cin, taps;
-  RowMap rm;
-  float* dW;       int ldw;               // [Nout, taps*Cin] fp32
-  int Nout;
-  int ctiles;                             // ceil(Cin / 128)
-  int steps_per_split, splits;            // reduction steps (KR rows each) per z-slice
-};
-
 template <typename T> struct WgradTraits;
 template <> struct WgradTraits<bf16_t> { static constexpr int KR = 32, ROWB = 288, CPR = 16, EPC = 8; };
 template <> struct WgradTraits<float>  { static constexpr int KR = 16, ROWB = 528, CPR = 32, EPC = 4; };
@@ -329,6 +283,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(GemmWgradParams p) {
         if (c >= p.Cin) continue;
         float* dst = p.dW + (size_t)n * p.ldw + (size_t)tap * p.Cin + c;
         if (p.splits > 1) atomicAdd(dst, acc[i][j][r]);
+        else if (p.accumulate) *dst += acc[i][j][r];
         else *dst = acc[i][j][r];
       }
     }
@@ -381,24 +336,10 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __re
   }
 }
 
-__global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ grad, int O, int I, int Ipad,
-                                    int taps, long so, long si, long st, int accumulate) {
-  long total = (long)O * I * taps;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    int tap = e % taps;
-    long r = e / taps;
-    int i = r % I;
-    long o = r / I;
-    float v = packed[(o * taps + tap) * Ipad + i];
-    float* dst = &grad[o * so + i * si + tap * st];
-    *dst = accumulate ? *dst + v : v;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-extern "C" int madiff_launch_gemm_fwd_bf16(const void* params, int out_f32, int grid_x, int grid_y, hipStream_t stream);
+extern "C" int madiff_launch_gemm_fwd_bf16(const void* params, int out_f32, int tile, hipStream_t stream);
 extern "C" int madiff_launch_gemm_wgrad_bf16(const void* params, int gx, int gy, int gz, hipStream_t stream);
 
 // MADIFF_GEMM_IMPL=0 forces the generic register-staged kernel for bf16 too (A/B timing, debugging)
@@ -412,14 +353,39 @@ static int check_rowmap(int T_out, int T_in, int stride, int pad, int tr) {
   return (T_out > 0 && T_in > 0 && stride > 0 && pad >= 0 && (tr == 0 || tr == 1)) ? 0 : -1;
 }
 
+// Default tile choice of the LDS-DMA kernel when the caller passes tile < 0 (the Python host autotunes per layer
+// shape and passes an explicit tile; this model is the fallback, e.g. under graph capture of an unseen shape).
+// Busiest CU holds nb = ceil(tiles / 256) workgroups; a lone workgroup runs at ~60 % of a CU's paired rate; smaller
+// tiles re-read more operand bytes per FLOP (eff).
+static const int kTileBM[6] = {128, 96, 64, 128, 96, 64};
+static const int kTileBN[6] = {128, 128, 128, 64, 64, 64};
+static int pick_tile(int M, int Npad, int wt) {
+  static const double eff[6] = {1.0, 0.93, 0.85, 0.85, 0.78, 0.70};
+  int best = 0;
+  double best_t = 1e300;
+  for (int t = 0; t < (wt ? 3 : 6); t++) {
+    const int BM = kTileBM[t], BN = kTileBN[t];
+    if (BN == 128 && Npad <= 64) continue;
+    long tiles = (long)((M + BM - 1) / BM) * ((Npad + BN - 1) / BN);
+    long nb = (tiles + 255) / 256;
+    double thr = nb >= 2 ? 1.0 : 0.6;
+    double cost = (double)nb * BM * BN / (thr * eff[t]);
+    if (cost < best_t * 0.999) { best_t = cost; best = t; }
+  }
+  return best;
+}
+
+extern "C" int madiff_gemm_tile_count(void) { return 6; }
+
 extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, const void* X2, int ldx2, int Csplit,
                                int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr,
                                const void* W, int ldw, int Nout, int Npad, const float* bias, const float* rowbias,
-                               int ldrb, void* C, int ldc, int act, int permT, int permA, hipStream_t stream) {
+                               int ldrb, void* C, int ldc, int act, int permT, int permA, int tile,
+                               hipStream_t stream) {
   const int KC = dtype == MADIFF_BF16 ? 32 : 16;
   if (M <= 0 || Nout <= 0) return 0;
   if (check_rowmap(T_out, T_in, stride, pad, tr) || Cin <= 0 || Cin % KC || taps <= 0 || Npad < Nout || ldc < Npad ||
-      ldw < taps * Cin || (ldw * (dtype == MADIFF_BF16 ? 2 : 4)) % 16 || ldx < 0 || M % T_out)
+      ldw < taps * Cin || (ldw * (dtype == MADIFF_BF16 ? 2 : 4)) % 16 || ldx < 0 || M % T_out || tile >= 6)
     return -1;
   if (X2 == nullptr) Csplit = Cin;
   if (Csplit % KC || Csplit > Cin || ldx < Csplit || (X2 && ldx2 < Cin - Csplit)) return -1;
@@ -431,9 +397,10 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Npad; p.bias = bias; p.rowbias = rowbias; p.ldrb = ldrb;
   p.C = C; p.ldc = ldc; p.act = act; p.permT = permT; p.permA = permA;
+  p.wt = 0; p.wtap = 0; p.wcols = 0;
   dim3 grid((M + 127) / 128, (Npad + 127) / 128), block(256);
   if (dtype == MADIFF_BF16 && Cin % 64 == 0 && Csplit % 64 == 0 && use_dma_kernel())
-    return madiff_launch_gemm_fwd_bf16(&p, out_f32, grid.x, grid.y, stream);
+    return madiff_launch_gemm_fwd_bf16(&p, out_f32, tile >= 0 ? tile : pick_tile(M, Npad, 0), stream);
   if (dtype == MADIFF_BF16) {
     if (out_f32) hipLaunchKernelGGL((gemm_fwd_kernel<bf16_t, float>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, stream, p);
@@ -444,9 +411,33 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   return 0;
 }
 
+// Data gradient of a layer straight from its FORWARD bf16 weight matrix W [Kred = Opad rows, ldw = taps*wtap]:
+//   dX[m, n] = sum_{tap, o} dY[src(m, tap), o] * W[o, tap*wtap + wcol0 + n],   n < Ncols
+// (gfx950 LDS-DMA kernel only; no transposed weight copy).  Requirements: bf16, Kred % 64 == 0 and every one of
+// the Kred rows of W is a real weight row; wcol0 % 8 == 0.  Returns 1 when the shape is not covered (the caller
+// then uses madiff_gemm_fwd on a transposed pack).
+extern "C" int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, int taps, int T_out, int T_in, int stride,
+                                    int pad, int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad,
+                                    void* dX, int ldx, int tile, hipStream_t stream) {
+  if (M <= 0 || Ncols <= 0) return 0;
+  if (!use_dma_kernel() || Kred % 64 || wcol0 % 8 || wtap % 8 || ldw % 8) return 1;
+  if (check_rowmap(T_out, T_in, stride, pad, tr) || taps <= 0 || ldy < Kred || ldy % 8 || Npad < Ncols || ldx < Npad ||
+      wcol0 < 0 || wcol0 + Ncols > wtap || ldw < taps * wtap || M % T_out || tile >= 3)
+    return -1;
+  GemmFwdParams p;
+  p.X = dY; p.ldx = ldy; p.X2 = nullptr; p.ldx2 = 0; p.Csplit = Kred;
+  p.M = M; p.Cin = Kred; p.taps = taps;
+  p.rm = RowMap{T_out, T_in, stride, pad, tr};
+  p.W = (const unsigned char*)W + (size_t)wcol0 * 2; p.ldw = ldw; p.Nout = Ncols; p.Npad = Npad;
+  p.bias = nullptr; p.rowbias = nullptr; p.ldrb = 0;
+  p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
+  p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0;
+  return madiff_launch_gemm_fwd_bf16(&p, 0, tile >= 0 ? tile : pick_tile(M, Npad, 1), stream);
+}
+
 extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2,
                                  int ldx2, int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride,
-                                 int pad, int tr, float* dW, int ldw, int Nout, hipStream_t stream) {
+                                 int pad, int tr, float* dW, int ldw, int Nout, int accumulate, hipStream_t stream) {
   const int es = dtype == MADIFF_BF16 ? 2 : 4;
   if (M <= 0 || Nout <= 0) return 0;
   if (check_rowmap(T_out, T_in, stride, pad, tr) || Cin <= 0 || Cin % 32 || taps <= 0 || ldw < taps * Cin ||
@@ -457,7 +448,7 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
   GemmWgradParams p;
   p.dY = dY; p.ldy = ldy; p.Ycols = Ycols; p.X = X; p.ldx = ldx; p.X2 = X2; p.ldx2 = ldx2; p.Csplit = Csplit;
   p.M = M; p.Cin = Cin; p.taps = taps; p.rm = RowMap{T_out, T_in, stride, pad, tr};
-  p.dW = dW; p.ldw = ldw; p.Nout = Nout;
+  p.dW = dW; p.ldw = ldw; p.Nout = Nout; p.accumulate = accumulate ? 1 : 0;
   p.ctiles = (Cin + 127) / 128;
   const bool dma = dtype == MADIFF_BF16 && use_dma_kernel() && T_out < 256 && M < (1 << 24);
   const int KR = dma ? 64 : (dtype == MADIFF_BF16 ? 32 : 16);
@@ -472,7 +463,7 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
   if (splits < 1) splits = 1;
   p.steps_per_split = (total_steps + splits - 1) / splits;
   p.splits = (total_steps + p.steps_per_split - 1) / p.steps_per_split;
-  if (p.splits > 1) {
+  if (p.splits > 1 && !p.accumulate) {
     hipError_t e = hipMemsetAsync(dW, 0, (size_t)Nout * ldw * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
   }
@@ -504,16 +495,6 @@ extern "C" int madiff_pack_weights_multi(int dtype, const long* table, int n_des
     hipLaunchKernelGGL((pack_weight_multi_kernel<bf16_t>), dim3(total_blocks), dim3(256), 0, stream, table, n_desc);
   else
     hipLaunchKernelGGL((pack_weight_multi_kernel<float>), dim3(total_blocks), dim3(256), 0, stream, table, n_desc);
-  MADIFF_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int madiff_unpack_wgrad(const float* packed, float* grad, int O, int I, int Ipad, int taps, long so, long si,
-                                   long st, int accumulate, hipStream_t stream) {
-  if (O <= 0 || I <= 0 || Ipad < I || taps <= 0) return -1;
-  long total = (long)O * I * taps;
-  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, packed, grad, O, I, Ipad, taps, so, si, st, accumulate);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

@@ -19,11 +19,12 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 _SIGS = {
     "madiff_gemm_fwd": [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i,
-                        _vp, _i, _i, _i, _i, _vp],
-    "madiff_gemm_wgrad": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
+                        _vp, _i, _i, _i, _i, _i, _vp],
+    "madiff_gemm_tile_count": [],
+    "madiff_gemm_dgrad_wt": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    "madiff_gemm_wgrad": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
     "madiff_pack_weight": [_i, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
     "madiff_pack_weights_multi": [_i, _vp, _i, _i, _vp],
-    "madiff_unpack_wgrad": [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _i, _vp],
     "madiff_gn_mish_fwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _i, _vp],
     "madiff_gn_mish_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_attn_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -41,7 +42,7 @@ _SIGS = {
     "madiff_act_bwd": [_i, _i, _vp, _vp, _vp, _l, _vp],
     "madiff_colsum": [_i, _vp, _i, _vp, _l, _i, _vp],
     "madiff_seqsum": [_i, _vp, _i, _vp, _i, _l, _i, _i, _vp],
-    "madiff_adam_ema": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp, _vp],
+    "madiff_adam_ema": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _i, _vp],
 }
 
 if not os.path.exists(LIB_PATH):
@@ -71,6 +72,18 @@ def call(name: str, *args) -> None:
     rc = getattr(_lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed with status {rc}" + (" (invalid argument)" if rc == -1 else " (hipError_t)"))
+
+
+def call_rc(name: str, *args) -> int:
+    """Call an entry point whose positive return values carry information (e.g. 1 = shape not covered)."""
+    rc = getattr(_lib, name)(*args)
+    if rc < 0 or rc > 1:
+        raise RuntimeError(f"{name} failed with status {rc}" + (" (invalid argument)" if rc == -1 else " (hipError_t)"))
+    return rc
+
+
+def tile_count() -> int:
+    return _lib.madiff_gemm_tile_count()
 
 
 def exported(name: str) -> bool:

@@ -89,23 +89,27 @@ def _strides(kind: str, w: torch.Tensor):
     """(O, I, so, si, st): element (o, i, tap) of the GEMM view lives at o*so + i*si + tap*st of the parameter."""
     if kind == "conv":
         O, I, k = w.shape
-        return O, I, I * k, k, 1
+        return O, I, w.stride(0), w.stride(1), w.stride(2)
     if kind == "convT":
         I, O, k = w.shape
-        return O, I, k, O * k, 1
+        return O, I, w.stride(1), w.stride(0), w.stride(2)
     O, I = w.shape
-    return O, I, I, 1, 0
+    return O, I, w.stride(0), w.stride(1), 0
 
 
 _PACK_CACHE: dict = {}
-_EPOCH = 0
+_EPOCH = 0        # bumped whenever parameter memory was written behind autograd's back
+_EPOCH_EXT = 0    # ... by anything but the fused optimizer (which keeps its bf16 shadow weights in sync itself)
 
 
-def params_changed() -> None:
+def params_changed(by_optimizer: bool = False) -> None:
     """Tell the pack cache that parameter memory was written behind autograd's back (e.g. by the fused
-    Adam kernel, which does not bump torch's version counters)."""
-    global _EPOCH
+    Adam kernel, which does not bump torch's version counters).  by_optimizer=True: the writer was
+    madiff_adam_ema, which refreshed the bf16 shadow of the flat buffer in the same pass."""
+    global _EPOCH, _EPOCH_EXT
     _EPOCH += 1
+    if not by_optimizer:
+        _EPOCH_EXT += 1
 
 
 PACK_EPB = 2048          # elements per block of madiff_pack_weights_multi (csrc/gemm.hip)
@@ -128,7 +132,7 @@ def _pack_jobs(weights, spec: ConvSpec, backward: bool, buf):
     es = buf.element_size()
     jobs, off = [], 0
     for w, (O, I_, so, si, st) in zip(weights, dims):
-        assert I_ == I and w.dtype == torch.float32 and w.is_contiguous()
+        assert I_ == I and w.dtype == torch.float32
         if backward:   # rows = i, cols = (tap, o): swap the roles of o and i
             jobs.append((w.data_ptr(), buf.data_ptr(), I, O, spec.taps, si, so, st, pad32(Osum), off))
         else:
@@ -178,6 +182,10 @@ def _packed(weights: Sequence[torch.Tensor], spec: ConvSpec, backward: bool) -> 
 
     forward : [sum O, taps * pad32(I)]        backward (data gradient): [I, taps * pad32(sum O)]
     """
+    if not backward and SINK is not None:
+        m = SINK.weight_matrix(weights, spec)
+        if m is not None:
+            return m
     key = (tuple(id(w) for w in weights), spec.kind, spec.taps, backward, _PRECISION)
     ent = _PACK_CACHE.get(key)
     if ent is not None and not all(r() is w for r, w in zip(ent.refs, weights)):
@@ -227,12 +235,13 @@ TIMER: Optional[KernelTimer] = None
 
 
 def _gemm_label(cin: int, csplit: int, out_f32: bool) -> str:
-    """Name of the kernel symbol madiff_gemm_fwd dispatches to (so bench.py's figures line up with rocprofv3's)."""
+    """Kernel template madiff_gemm_fwd dispatches to (so bench.py's figures line up with rocprofv3's names; every tile
+    shape / output type / weight-layout instantiation of the LDS-DMA kernel is reported under one name)."""
     if _PRECISION != "bf16":
         return "gemm_fwd_kernel<float,float>"
     if cin % 64 == 0 and csplit % 64 == 0 and os.environ.get("MADIFF_GEMM_IMPL", "1") != "0":
-        return "gemm_fwd_bf16_kernel<float>" if out_f32 else "gemm_fwd_bf16_kernel<bf16>"
-    return "gemm_fwd_kernel<bf16,float>" if out_f32 else "gemm_fwd_kernel<bf16,bf16>"
+        return "gemm_fwd_bf16_kernel"
+    return "gemm_fwd_kernel<bf16,*>"
 
 
 def _timed(name: str, flops: float, launch):
@@ -249,19 +258,76 @@ def _timed(name: str, flops: float, launch):
 # ------------------------------------------------------------------------------------------------
 # raw launches
 # ------------------------------------------------------------------------------------------------
+_TUNE: dict = {}
+_AUTOTUNE = os.environ.get("MADIFF_AUTOTUNE", "1") != "0"
+
+
+def _tuned_tile(sig, n_tiles: int, launch) -> int:
+    """Output tile of the LDS-DMA GEMM for one layer shape.  The first time a shape is seen (outside graph capture)
+    every tile the library offers is timed on the real operands and the fastest is remembered; results do not depend
+    on the tile (same reduction order per output element), so this is a pure speed choice.  -1 = library's model."""
+    t = _TUNE.get(sig)
+    if t is not None:
+        return t
+    if not _AUTOTUNE or _PRECISION != "bf16" or torch.cuda.is_current_stream_capturing():
+        return -1
+    best, best_ms = -1, float("inf")
+    for tile in range(n_tiles):
+        launch(tile)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            launch(tile)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if ms < best_ms:
+            best, best_ms = tile, ms
+    _TUNE[sig] = best
+    return best
+
+
 def _gemm(x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, tr, W, nout, npad, bias, rowbias, out, act=0,
           perm: Optional[Tuple[int, int]] = None):
     out_f32 = 1 if (out.dtype == torch.float32 and _PRECISION == "bf16") else 0
-    lib.call("madiff_gemm_fwd", _dt(), out_f32, x.data_ptr(), x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0),
-             csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad, tr, W.data_ptr(), W.stride(0), nout, npad,
-             _p(bias), _p(rowbias), 0 if rowbias is None else rowbias.stride(0), out.data_ptr(), out.stride(0), act,
-             perm[0] if perm else 0, perm[1] if perm else 0, _stream())
+    dma = _PRECISION == "bf16" and cin % 64 == 0 and csplit % 64 == 0
+
+    def launch(tile):
+        lib.call("madiff_gemm_fwd", _dt(), out_f32, x.data_ptr(), x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0),
+                 csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad, tr, W.data_ptr(), W.stride(0), nout, npad,
+                 _p(bias), _p(rowbias), 0 if rowbias is None else rowbias.stride(0), out.data_ptr(), out.stride(0), act,
+                 perm[0] if perm else 0, perm[1] if perm else 0, tile, _stream())
+
+    tile = _tuned_tile(("fwd", M, cin, spec.taps, npad, t_out, spec.stride, tr, out_f32, x2 is not None),
+                       lib.tile_count(), launch) if dma else -1
+    launch(tile)
 
 
-def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout):
+def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncols, gx) -> bool:
+    """Data gradient straight from the forward-layout bf16 weights (no transposed pack).  False: shape not covered."""
+    def launch(tile):
+        return lib.call_rc("madiff_gemm_dgrad_wt", dy.data_ptr(), dy.stride(0), M_in, npad, spec.taps, t_in, t_out,
+                           spec.stride, spec.pad, 1 - spec.tr, Wf.data_ptr(), Wf.stride(0), wtap, wcol0, ncols,
+                           gx.shape[1], gx.data_ptr(), gx.stride(0), tile, _stream())
+
+    sig = ("wt", M_in, npad, spec.taps, gx.shape[1], t_in, spec.stride, spec.tr)
+    tile = _TUNE.get(sig)
+    if tile is None:
+        if launch(-1) != 0:          # probe = the real launch with the library's default tile
+            _TUNE[sig] = "uncovered"
+            return False
+        _tuned_tile(sig, 3, launch)  # remembers the fastest tile for the next call (no-op under capture / when disabled)
+        return True
+    if tile == "uncovered":
+        return False
+    launch(tile)
+    return True
+
+
+def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, accumulate=0):
     lib.call("madiff_gemm_wgrad", _dt(), dy.data_ptr(), dy.stride(0), dy.shape[1], x.data_ptr(), x.stride(0), _p(x2),
              0 if x2 is None else x2.stride(0), csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad, spec.tr,
-             dW.data_ptr(), dW.stride(0), nout, _stream())
+             dW.data_ptr(), dW.stride(0), nout, accumulate, _stream())
 
 
 def pack_traj(x: torch.Tensor, fpad: int, noise=None, t=None, sqrt_ac=None, sqrt_1mac=None, cond=None, mask=None,
@@ -289,18 +355,34 @@ def unpack_traj(xcl: torch.Tensor, B, T, A, F) -> torch.Tensor:
 # gradient sinks: let backward kernels accumulate straight into the optimizer's flat gradient buffer
 # ------------------------------------------------------------------------------------------------
 class GradSink:
-    """Maps a parameter to a live fp32 gradient view (same shape, contiguous).  When installed (ops.SINK), the
-    backward kernels ACCUMULATE parameter gradients into these views and return None to autograd, which removes
-    one temporary, one zero-fill and one `grad += new` pass per parameter.  `notify(param)` is called after the
-    write (the data-parallel optimizer counts bucket readiness there)."""
+    """Maps a parameter to a live fp32 gradient view (same shape).  When installed (ops.SINK), the backward kernels
+    ACCUMULATE parameter gradients into these views and return None to autograd, which removes one temporary, one
+    zero-fill and one `grad += new` pass per parameter.  `notify(param)` is called after the write (the
+    data-parallel optimizer counts bucket readiness there).
+
+    GEMM-layout slots (the flat optimizer keeps every weight MATRIX as [O, taps, pad32(I)] inside its flat buffers):
+    `register_matrix` records the slot, after which
+      * weight_matrix(group) is the GEMM's forward weight operand itself -- the fp32 flat parameter buffer in the
+        fp32 build, its bf16 shadow (maintained by madiff_adam_ema) in the bf16 build: no pack pass;
+      * grad_matrix(group) is the [sum O, taps*pad32(I)] slice of the flat gradient the weight-gradient GEMM
+        accumulates into directly: no unpack pass.
+    A group (layers sharing their input, e.g. q/k/v) is served when its members sit back to back in the flat buffer.
+    """
 
     def __init__(self):
         self.views = {}
         self.notify = None
+        self.flat_p = self.flat_g = self.flat_p16 = None
+        self.slots = {}          # id(param) -> (weakref, offset, O, K, kind, taps)
+        self.shadow_state = {}   # id(param) -> (param._version, _EPOCH_EXT) at which the bf16 shadow was in sync
+        self._groups = {}
 
     def register(self, param, view):
-        assert view.dtype == torch.float32 and view.is_contiguous() and view.shape == param.shape
+        assert view.dtype == torch.float32 and view.shape == param.shape
         self.views[id(param)] = (weakref.ref(param), view)
+
+    def register_matrix(self, param, offset: int, O: int, K: int, kind: str, taps: int):
+        self.slots[id(param)] = (weakref.ref(param), offset, O, K, kind, taps)
 
     def get(self, param):
         ent = self.views.get(id(param))
@@ -311,6 +393,78 @@ class GradSink:
     def done(self, param):
         if self.notify is not None:
             self.notify(param)
+
+    def _group(self, weights, spec):
+        """(offset, sum O, K) when `weights` occupy consecutive GEMM-layout slots matching `spec`, else None."""
+        key = (tuple(id(w) for w in weights), spec.kind, spec.taps)
+        g = self._groups.get(key)
+        if g is not None and all(self.slots[id(w)][0]() is w for w in weights):
+            return g
+        off0 = nxt = K0 = None
+        osum = 0
+        for w in weights:
+            sl = self.slots.get(id(w))
+            if sl is None or sl[0]() is not w or sl[4] != spec.kind or sl[5] != spec.taps:
+                return None
+            _, off, O, K, _, _ = sl
+            if off0 is None:
+                off0, K0 = off, K
+            elif off != nxt or K != K0:
+                return None
+            nxt = off + O * K
+            osum += O
+        g = (off0, osum, K0)
+        self._groups[key] = g
+        return g
+
+    def weight_matrix(self, weights, spec):
+        if self.flat_p is None:
+            return None
+        g = self._group(weights, spec)
+        if g is None:
+            return None
+        off, osum, K = g
+        if _PRECISION == "fp32":
+            return self.flat_p[off:off + osum * K].view(osum, K)      # the parameter memory itself
+        if self.flat_p16 is None:
+            return None
+        cur_ext = _EPOCH_EXT
+        for w in weights:
+            if self.shadow_state.get(id(w)) != (w._version, cur_ext):
+                self._refresh_shadow(w)
+        return self.flat_p16[off:off + osum * K].view(osum, K)
+
+    def _refresh_shadow(self, w):
+        """The parameter was written by something other than the fused optimizer (load_state_dict, broadcast, ...)."""
+        _, off, O, K, kind, taps = self.slots[id(w)]
+        O_, I, so, si, st = _strides(kind, w)
+        lib.call("madiff_pack_weight", lib.BF16, w.data_ptr(), self.flat_p16.data_ptr() + 2 * off, O, I, taps, so, si, st,
+                 K // taps, 0, _stream())
+        self.shadow_state[id(w)] = (w._version, _EPOCH_EXT)
+
+    def grad_matrix(self, weights, spec):
+        if self.flat_g is None:
+            return None
+        g = self._group(weights, spec)
+        if g is None:
+            return None
+        off, osum, K = g
+        return self.flat_g[off:off + osum * K].view(osum, K)
+
+
+def known_gemm_weights():
+    """{id(param): (kind, taps, group ids)} for every parameter the GEMM layers have used so far (from the pack cache);
+    the flat optimizer lays its buffers out from this after the first forward/backward."""
+    out = {}
+    for (ids, kind, taps, backward, _prec), ent in _PACK_CACHE.items():
+        ws = [r() for r in ent.refs]
+        if any(w is None for w in ws):
+            continue
+        for w in ws:
+            prev = out.get(id(w))
+            if prev is None or len(ids) > len(prev[2]):
+                out[id(w)] = (kind, taps, ids)
+    return out
 
 
 SINK: Optional[GradSink] = None
@@ -374,8 +528,9 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
     M, M_in, npad = n_seq * t_out, n_seq * t_in, pad32(osum)
     dx = dx2 = drb = None
     if need_dx or (x2 is not None and need_dx2):
-        Wb = _packed(weights, spec, True)          # [I, taps * npad]
-        es = Wb.element_size()
+        # bf16 build: the data gradient reads the FORWARD weight matrix through transposing LDS reads
+        Wf = _packed(weights, spec, False) if (_PRECISION == "bf16" and npad % 64 == 0 and osum == npad) else None
+        Wb = None
         parts = [(0, c1 if x2 is not None else I, need_dx)]
         if x2 is not None:
             parts.append((c1, I - c1, need_dx2))
@@ -385,31 +540,50 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
                 grads.append(None)
                 continue
             gx = torch.empty(M_in, pad32(rows), dtype=act_dtype(), device=dy.device)
-            _timed(_gemm_label(npad, npad, False), g.flops * rows / I, lambda: lib.call(
-                "madiff_gemm_fwd", _dt(), 0, dy.data_ptr(), dy.stride(0), None, 0, npad, M_in, npad, spec.taps,
-                t_in, t_out, spec.stride, spec.pad, 1 - spec.tr, Wb.data_ptr() + row0 * Wb.stride(0) * es,
-                Wb.stride(0), rows, pad32(rows), None, None, 0, gx.data_ptr(), gx.stride(0), 0, 0, 0, _stream()))
+            done = [False]
+
+            def run_wt():
+                done[0] = _dgrad_wt(dy, M_in, npad, spec, t_in, t_out, Wf, cin, row0, rows, gx)
+
+            if Wf is not None:
+                _timed("gemm_fwd_bf16_kernel", g.flops * rows / I, run_wt)
+            if not done[0]:
+                if Wb is None:
+                    Wb = _packed(weights, spec, True)          # [I, taps * npad]
+                es = Wb.element_size()
+                _timed(_gemm_label(npad, npad, False), g.flops * rows / I, lambda: lib.call(
+                    "madiff_gemm_fwd", _dt(), 0, dy.data_ptr(), dy.stride(0), None, 0, npad, M_in, npad, spec.taps,
+                    t_in, t_out, spec.stride, spec.pad, 1 - spec.tr, Wb.data_ptr() + row0 * Wb.stride(0) * es,
+                    Wb.stride(0), rows, pad32(rows), None, None, 0, gx.data_ptr(), gx.stride(0), 0, 0, 0, -1, _stream()))
             grads.append(gx)
         dx = grads[0]
         if x2 is not None:
             dx2 = grads[1]
     gw: List[Optional[torch.Tensor]] = [None] * len(weights)
     if any(need_w):
-        dW = torch.empty(osum, spec.taps * cin, dtype=torch.float32, device=dy.device)
-        _timed("gemm_wgrad_bf16_kernel" if _PRECISION == "bf16" else "gemm_wgrad_kernel<float>", g.flops,
-               lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum))
-        off = 0
-        for i, (w, (O, I_, so, si, st)) in enumerate(zip(weights, g.dims)):
-            if need_w[i]:
-                view = _sink_view(w)
-                dst = view if view is not None else torch.empty_like(w)
-                lib.call("madiff_unpack_wgrad", dW.data_ptr() + off * dW.stride(0) * 4, dst.data_ptr(), O, I_, cin,
-                         spec.taps, so, si, st, int(view is not None), _stream())
-                if view is None:
-                    gw[i] = dst
-                else:
-                    SINK.done(w)
-            off += O
+        wlabel = "gemm_wgrad_bf16_kernel" if _PRECISION == "bf16" else "gemm_wgrad_kernel<float>"
+        gm = SINK.grad_matrix(weights, spec) if (SINK is not None and all(need_w)) else None
+        if gm is not None:       # accumulate straight into the flat gradient (kept in this GEMM layout)
+            assert gm.shape == (osum, spec.taps * cin)
+            _timed(wlabel, g.flops, lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, gm, osum, 1))
+            for w in weights:
+                SINK.done(w)
+        else:
+            dW = torch.empty(osum, spec.taps * cin, dtype=torch.float32, device=dy.device)
+            _timed(wlabel, g.flops, lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum, 0))
+            off = 0
+            for i, (w, (O, I_, so, si, st)) in enumerate(zip(weights, g.dims)):
+                if need_w[i]:
+                    gv = dW[off:off + O].view(O, spec.taps, cin)[:, :, :I_]     # GEMM layout -> the parameter's shape
+                    gv = gv.permute(0, 2, 1) if spec.kind == "conv" else (gv.permute(2, 0, 1) if spec.kind == "convT"
+                                                                          else gv[:, 0, :])
+                    view = _sink_view(w)
+                    if view is not None:
+                        view.add_(gv)
+                        SINK.done(w)
+                    else:
+                        gw[i] = gv
+                off += O
     gb: List[Optional[torch.Tensor]] = [None] * len(biases)
     if biases and bias_mode == "colsum":
         if len(biases) == 1 and _sink_view(biases[0]) is not None:

@@ -55,11 +55,53 @@ class FlatAdamEMA:
         dev = self.params[0].device
         if self.use_hip is None:
             self.use_hip = dev.type == "cuda"
-        offs, total = [], 0
+        # ---- flat layout.  Weight matrices of GEMM layers are stored in the GEMM's own layout [O, taps, pad32(I)]
+        # (pad columns stay 0: zero gradient -> zero Adam update), members of a fused group (q/k/v, the time-MLP
+        # bundle) back to back; the nn.Parameter becomes a strided view with the reference's shape.  Adam/EMA are
+        # elementwise, so the layout is free for them, and the GEMMs then need no pack/unpack pass at all.
+        known = ops.known_gemm_weights() if self.use_hip else {}
+        by_id = {id(p): (n, p) for n, p in named}
+        order, seen = [], set()
+        for n, p in named:
+            if id(p) in seen:
+                continue
+            info = known.get(id(p))
+            members = [p]
+            if info is not None and len(info[2]) > 1 and all(i in by_id for i in info[2]):
+                members = [by_id[i][1] for i in info[2]]
+            for q in members:
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    order.append(q)
+        name_of = {id(p): n for n, p in named}
+        self.params = order
+        self.names = [name_of[id(p)] for p in order]
+        offs, total, geoms = [], 0, []
         for p in self.params:
             offs.append(total)
-            total += (p.numel() + 3) // 4 * 4          # keep every slice 16-byte aligned
-        self.offsets, self.total = offs, total
+            info = known.get(id(p))
+            if info is not None:
+                kind, taps, _ = info
+                O, I = (p.shape[0], p.shape[1]) if kind != "convT" else (p.shape[1], p.shape[0])
+                ipad = ops.pad32(I)
+                geoms.append((kind, taps, O, I, ipad))
+                total += O * taps * ipad
+            else:
+                geoms.append(None)
+                total += (p.numel() + 3) // 4 * 4      # keep every slice 16-byte aligned
+        self.offsets, self.total, self.geoms = offs, total, geoms
+
+        def view_of(flat, o, p, geom):
+            if geom is None:
+                return flat[o:o + p.numel()].view_as(p)
+            kind, taps, O, I, ipad = geom
+            v = flat[o:o + O * taps * ipad].view(O, taps, ipad)[:, :, :I]
+            if kind == "conv":
+                return v.permute(0, 2, 1)
+            if kind == "convT":
+                return v.permute(2, 0, 1)
+            return v[:, 0, :]
+
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -67,17 +109,21 @@ class FlatAdamEMA:
         ema_named: Dict[str, torch.nn.Parameter] = dict(self.ema_module.named_parameters()) if self.ema_module is not None else {}
         if self.ema_module is not None:
             self.flat_ema = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad_views = []
         with torch.no_grad():
-            for n, p, o in zip(self.names, self.params, offs):
-                k = p.numel()
-                self.flat_p[o:o + k].copy_(p.detach().reshape(-1))
-                self.flat_g[o:o + k].copy_(p.grad.reshape(-1))
-                p.data = self.flat_p[o:o + k].view_as(p)
-                p.grad = self.flat_g[o:o + k].view_as(p)
+            for n, p, o, geom in zip(self.names, self.params, offs, geoms):
+                pv, gv = view_of(self.flat_p, o, p, geom), view_of(self.flat_g, o, p, geom)
+                pv.copy_(p.detach())
+                gv.copy_(p.grad)
+                p.data = pv
+                p.grad = gv
+                self.grad_views.append(gv)
                 if self.ema_module is not None:
                     e = ema_named[n]
-                    self.flat_ema[o:o + k].copy_(e.detach().reshape(-1))
-                    e.data = self.flat_ema[o:o + k].view_as(e)
+                    ev = view_of(self.flat_ema, o, e, geom)
+                    ev.copy_(e.detach())
+                    e.data = ev
+        ops.clear_pack_cache()
         ops.params_changed()
         # buckets: contiguous slices, cut from the END of the flat buffer (first gradients backward produces)
         self.buckets = []
@@ -103,10 +149,18 @@ class FlatAdamEMA:
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         if self.use_hip:
-            # backward kernels accumulate parameter gradients straight into the flat buffer (ops.GradSink)
+            # backward kernels accumulate parameter gradients straight into the flat buffer (ops.GradSink); the GEMMs
+            # read / write the GEMM-layout slots of the flat buffers directly
             sink = ops.GradSink()
-            for p, o in zip(self.params, offs):
-                sink.register(p, self.flat_g[o:o + p.numel()].view_as(p))
+            sink.flat_p, sink.flat_g = self.flat_p, self.flat_g
+            self.flat_p16 = self.flat_p.to(torch.bfloat16)      # bf16 shadow, kept in sync by madiff_adam_ema
+            sink.flat_p16 = self.flat_p16
+            for p, o, geom, gv in zip(self.params, offs, geoms, self.grad_views):
+                sink.register(p, gv)
+                if geom is not None:
+                    kind, taps, O, I, ipad = geom
+                    sink.register_matrix(p, o, O, taps * ipad, kind, taps)
+                    sink.shadow_state[id(p)] = (p._version, ops._EPOCH_EXT)
             if self.world > 1:
                 hooks = [self._make_hook(i) for i in range(len(self.params))]
                 sink.notify = lambda p: hooks[self._index[id(p)]](p)
@@ -134,7 +188,9 @@ class FlatAdamEMA:
     # ------------------------------------------------------------------ per-step API
     def zero_grad(self):
         if self.flat_g is not None:
-            self.flat_g.zero_()
+            if not getattr(self, "_grads_zeroed", False):   # the fused Adam kernel clears the gradient as it reads it
+                self.flat_g.zero_()
+            self._grads_zeroed = False
         else:
             for p in self.module.parameters():
                 p.grad = None
@@ -177,8 +233,9 @@ class FlatAdamEMA:
             lib.call("madiff_adam_ema", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                      self.flat_v.data_ptr(), None if self.flat_ema is None else self.flat_ema.data_ptr(), self.total,
                      self.lr, b1, b2, self.eps, bc1, bc2s, scale, do_ema, self.ema_decay, None,
-                     torch.cuda.current_stream().cuda_stream)
-            ops.params_changed()
+                     self.flat_p16.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+            self._grads_zeroed = True
+            ops.params_changed(by_optimizer=True)
         else:   # host arithmetic for the gloo/CPU tests of the data-parallel machinery only
             with torch.no_grad():
                 g = self.flat_g * scale

@@ -1,11 +1,13 @@
-"""Micro-benchmark of the implicit-GEMM kernels on the layer shapes of the bench workload (B=256, A=4 -> N=1024)."""
-import os, sys, time
+"""Micro-benchmark of the implicit-GEMM kernels on the layer shapes of the bench workload (B=256, A=4 -> N=1024):
+forward for every output tile the library offers, data gradient from the forward weight layout (3 tiles), weight
+gradient.  Prints TFLOP/s per variant and the per-step totals with the best tile of each layer."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from madiff_amd import ops
 ops.set_precision("bf16")
 dev = torch.device("cuda:0")
-N = 1024
+N = int(os.environ.get("NSEQ", 1024))
 # (name, T, Cin, Cout, spec, count per forward)
 shapes = [("T2 1024->1024 k5", 6, 1024, 1024, ops.CONV5, 7), ("T2 2048->512 k5", 6, 2048, 512, ops.CONV5, 1),
           ("T2 512->1024 k5", 6, 512, 1024, ops.CONV5, 1), ("T2 512->512 k5", 6, 512, 512, ops.CONV5, 3),
@@ -16,31 +18,50 @@ shapes = [("T2 1024->1024 k5", 6, 1024, 1024, ops.CONV5, 7), ("T2 2048->512 k5",
           ("T2 512->1024 1x1", 6, 512, 1024, ops.CONV1, 1), ("T2 2048->512 1x1", 6, 2048, 512, ops.CONV1, 1),
           ("T1 128->512 1x1", 12, 128, 512, ops.CONV1, 1), ("T1 1024->128 1x1", 12, 1024, 128, ops.CONV1, 1)]
 tot = [0.0, 0.0, 0.0]
+TILES = ["128x128", "96x128", "64x128", "128x64", "96x64", "64x64"]
+
+
 def timeit(fn, n=20):
-    for _ in range(3): fn()
+    for _ in range(3):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
+
+
 for name, T, ci, co, spec, cnt in shapes:
-    x = torch.randn(N * T, ci, device=dev).to(torch.bfloat16).requires_grad_(True)
-    w = (torch.randn(co, ci, spec.taps, device=dev) / (ci * spec.taps) ** 0.5).requires_grad_(True)
-    b = torch.zeros(co, device=dev, requires_grad=True)
-    y = ops.conv_gemm(x, [w], [b], spec, T)
-    gy = torch.randn_like(y)
-    flops = 2.0 * N * T * ci * co * spec.taps
-    tf = timeit(lambda: ops.conv_gemm(x.detach(), [w], [b], spec, T))
-    # backward pieces, timed through the raw launches
-    Wb = ops._packed([w], spec, True)
-    dx = torch.empty(N * T, ci, dtype=torch.bfloat16, device=dev)
-    def dgrad():
-        ops.lib.call("madiff_gemm_fwd", 1, 0, gy.data_ptr(), gy.stride(0), None, 0, gy.shape[1], N * T, gy.shape[1], spec.taps,
-                     T, T, 1, spec.pad, 1, Wb.data_ptr(), Wb.stride(0), ci, ci, None, None, 0, dx.data_ptr(), dx.stride(0), 0, 0, 0, ops._stream())
-    td = timeit(dgrad)
+    M = N * T
+    x = torch.randn(M, ci, device=dev).to(torch.bfloat16)
+    w = (torch.randn(co, ci, spec.taps, device=dev) / (ci * spec.taps) ** 0.5)
+    Wf = ops._packed([w], spec, False)
+    y = torch.empty(M, co, dtype=torch.bfloat16, device=dev)
+    gy = torch.randn(M, co, device=dev).to(torch.bfloat16)
+    dx = torch.empty(M, ci, dtype=torch.bfloat16, device=dev)
+    flops = 2.0 * M * ci * co * spec.taps
+    st = ops._stream()
+    fw = []
+    for tile in range(6):
+        fw.append(timeit(lambda: ops.lib.call("madiff_gemm_fwd", 1, 0, x.data_ptr(), ci, None, 0, ci, M, ci, spec.taps, T, T,
+                                              1, spec.pad, 0, Wf.data_ptr(), Wf.stride(0), co, co, None, None, 0,
+                                              y.data_ptr(), co, 0, 0, 0, tile, st)))
+    dg = []
+    for tile in range(3):
+        dg.append(timeit(lambda: ops.lib.call_rc("madiff_gemm_dgrad_wt", gy.data_ptr(), co, M, co, spec.taps, T, T, 1,
+                                                 spec.pad, 1, Wf.data_ptr(), Wf.stride(0), ci, 0, ci, ci, dx.data_ptr(),
+                                                 ci, tile, st)))
     dW = torch.empty(co, spec.taps * ci, dtype=torch.float32, device=dev)
-    tw = timeit(lambda: ops._wgrad(gy, x.detach(), None, ci, N * T, ci, spec, T, T, dW, co))
-    tot[0] += cnt * tf; tot[1] += cnt * td; tot[2] += cnt * tw
-    print(f"{name:22s} x{cnt} fwd {tf*1e3:7.1f} us {flops/tf/1e9:7.1f} TF | dgrad {td*1e3:7.1f} us {flops/td/1e9:7.1f} TF | wgrad {tw*1e3:7.1f} us {flops/tw/1e9:7.1f} TF", flush=True)
+    tw = timeit(lambda: ops._wgrad(gy, x, None, ci, M, ci, spec, T, T, dW, co))
+    tot[0] += cnt * min(fw)
+    tot[1] += cnt * min(dg)
+    tot[2] += cnt * tw
+    f = " ".join(f"{flops / t / 1e9:6.0f}" for t in fw)
+    d = " ".join(f"{flops / t / 1e9:6.0f}" for t in dg)
+    print(f"{name:20s} x{cnt} fwd TF [{f}] best {TILES[fw.index(min(fw))]:>7s} {min(fw) * 1e3:6.1f} us | dgrad_wt TF [{d}] "
+          f"{min(dg) * 1e3:6.1f} us | wgrad {tw * 1e3:6.1f} us {flops / tw / 1e9:6.0f} TF", flush=True)
+print("tiles:", TILES)
 print(f"weighted totals per step (ms): fwd {tot[0]:.3f} dgrad {tot[1]:.3f} wgrad {tot[2]:.3f}")
