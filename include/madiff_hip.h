@@ -40,29 +40,36 @@ const char* madiff_arch(void);
  * (temporal.py:74-88,177-181,231-251; models/diffusion.py:111-119) and their data gradients.
  * act: 0 none, 1 relu, 2 mish.  permA > 0 stores rows (b, a, t) as (b, t, a) (the "b a f t -> b t a f" of
  * models/ma_temporal.py:416).  out_f32 != 0 writes fp32 output in the bf16 build.
- * tile: output tile of the gfx950 LDS-DMA kernel, 0..madiff_gemm_tile_count()-1 = {128x128, 96x128, 64x128, 128x64,
- * 96x64, 64x64}; < 0 lets the library choose.  Results do not depend on the tile. */
+ * tile: variant (output tile x LDS pipeline depth) of the gfx950 LDS-DMA kernel, 0..madiff_gemm_tile_count()-1, described
+ * by madiff_gemm_tile_info; < 0 lets the library choose.  Results do not depend on the variant. */
 int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, const void* X2, int ldx2, int Csplit, int M, int Cin,
                     int taps, int T_out, int T_in, int stride, int pad, int tr, const void* W, int ldw, int Nout, int Npad,
                     const float* bias, const float* rowbias, int ldrb, void* C, int ldc, int act, int permT, int permA,
                     int tile, madiff_stream_t stream);
 int madiff_gemm_tile_count(void);
+/* rows / columns / LDS stages of variant `tile`; returns 1 when madiff_gemm_dgrad_wt offers it too, 0 when not, -1 when
+ * the id is invalid. */
+int madiff_gemm_tile_info(int tile, int* bm, int* bn, int* stages);
 
 /* Data gradient of the same modules (the dgrad half of autograd for nn.Conv1d / ConvTranspose1d / Linear) computed
  * straight from the FORWARD bf16 weight matrix W [Kred rows = output channels, ldw = taps*wtap]:
  *   dX[m, n] = sum_{tap, o} dY[src(m, tap), o] * W[o, tap*wtap + wcol0 + n],  n < Ncols (pad columns up to Npad are 0).
  * bf16 only; returns 1 (nothing launched) when the shape is not covered (Kred % 64 != 0): the caller then runs
- * madiff_gemm_fwd on a transposed weight pack.  tile: 0..2 = {128x128, 96x128, 64x128}, < 0 = library's choice. */
+ * madiff_gemm_fwd on a transposed weight pack.  tile: a variant for which madiff_gemm_tile_info returns 1, < 0 =
+ * library's choice.  ksplit > 1 cuts the reduction into slices combined with fp32 atomics: dX is then FP32 [M, ldx]
+ * (for few-row, long-reduction shapes such as the time-MLP bundle). */
 int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, int taps, int T_out, int T_in, int stride, int pad,
                          int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad, void* dX, int ldx,
-                         int tile, madiff_stream_t stream);
+                         int tile, int ksplit, madiff_stream_t stream);
 
 /* Weight gradient of the above: dW[o, tap*Cin + c] (+)= sum_m dY[m, o] * X[src(m, tap), c]  (fp32 output).
  * Replaces the wgrad half of autograd for the same modules.  accumulate != 0 adds into dW (a live gradient buffer
- * kept in this GEMM layout by the flat optimizer), 0 overwrites. */
+ * kept in this GEMM layout by the flat optimizer), 0 overwrites.  tile: output tile (O x C) of the gfx950 LDS-DMA kernel,
+ * 0..3 = {128x128, 128x64, 64x128, 64x64}, < 0 = library's choice; splits: number of slices the reduction over rows is
+ * cut into (slices combine with fp32 atomics), <= 0 = library's choice. */
 int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,
                       int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,
-                      int ldw, int Nout, int accumulate, madiff_stream_t stream);
+                      int ldw, int Nout, int accumulate, int tile, int splits, madiff_stream_t stream);
 
 /* Parameter layout (fp32, element (o, i, tap) at o*so + i*si + tap*st) <-> GEMM layout [O, taps, Ipad].
  * pack writes dst[(o*taps + tap)*dst_ld + dst_off + i] and leaves pad columns alone (buffer is zero-filled once). */

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __re
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int madiff_launch_gemm_fwd_bf16(const void* params, int out_f32, int tile, hipStream_t stream);
-extern "C" int madiff_launch_gemm_wgrad_bf16(const void* params, int gx, int gy, int gz, hipStream_t stream);
+extern "C" int madiff_launch_gemm_wgrad_bf16(const void* params, int tile, int gx, int gy, int gz, hipStream_t stream);
 
 // MADIFF_GEMM_IMPL=0 forces the generic register-staged kernel for bf16 too (A/B timing, debugging)
 static int use_dma_kernel() {
@@ -357,8 +357,10 @@ static int check_rowmap(int T_out, int T_in, int stride, int pad, int tr) {
 // shape and passes an explicit tile; this model is the fallback, e.g. under graph capture of an unseen shape).
 // Busiest CU holds nb = ceil(tiles / 256) workgroups; a lone workgroup runs at ~60 % of a CU's paired rate; smaller
 // tiles re-read more operand bytes per FLOP (eff).
-static const int kTileBM[6] = {128, 96, 64, 128, 96, 64};
-static const int kTileBN[6] = {128, 128, 128, 64, 64, 64};
+static const int kNumTiles = 14;
+static const int kTileBM[kNumTiles] = {128, 96, 64, 128, 96, 64, 128, 96, 64, 128, 96, 64, 64, 64};
+static const int kTileBN[kNumTiles] = {128, 128, 128, 64, 64, 64, 128, 128, 128, 64, 64, 64, 128, 64};
+static const int kTileD[kNumTiles] = {2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4};
 static int pick_tile(int M, int Npad, int wt) {
   static const double eff[6] = {1.0, 0.93, 0.85, 0.85, 0.78, 0.70};
   int best = 0;
@@ -372,10 +374,19 @@ static int pick_tile(int M, int Npad, int wt) {
     double cost = (double)nb * BM * BN / (thr * eff[t]);
     if (cost < best_t * 0.999) { best_t = cost; best = t; }
   }
-  return best;
+  return best >= 1 ? best + 6 : best;      // three LDS stages for every shape but 128x128 (one workgroup per CU there)
 }
 
-extern "C" int madiff_gemm_tile_count(void) { return 6; }
+extern "C" int madiff_gemm_tile_count(void) { return kNumTiles; }
+// rows / columns / LDS stages of kernel variant `tile`; returns 1 when the variant also exists for the transposed-weight
+// data-gradient kernel (madiff_gemm_dgrad_wt), 0 when not, -1 for an invalid id
+extern "C" int madiff_gemm_tile_info(int tile, int* bm, int* bn, int* stages) {
+  if (tile < 0 || tile >= kNumTiles) return -1;
+  if (bm) *bm = kTileBM[tile];
+  if (bn) *bn = kTileBN[tile];
+  if (stages) *stages = kTileD[tile];
+  return kTileBN[tile] == 128 ? 1 : 0;
+}
 
 extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, const void* X2, int ldx2, int Csplit,
                                int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr,
@@ -385,7 +396,7 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   const int KC = dtype == MADIFF_BF16 ? 32 : 16;
   if (M <= 0 || Nout <= 0) return 0;
   if (check_rowmap(T_out, T_in, stride, pad, tr) || Cin <= 0 || Cin % KC || taps <= 0 || Npad < Nout || ldc < Npad ||
-      ldw < taps * Cin || (ldw * (dtype == MADIFF_BF16 ? 2 : 4)) % 16 || ldx < 0 || M % T_out || tile >= 6)
+      ldw < taps * Cin || (ldw * (dtype == MADIFF_BF16 ? 2 : 4)) % 16 || ldx < 0 || M % T_out || tile >= kNumTiles)
     return -1;
   if (X2 == nullptr) Csplit = Cin;
   if (Csplit % KC || Csplit > Cin || ldx < Csplit || (X2 && ldx2 < Cin - Csplit)) return -1;
@@ -397,7 +408,7 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Npad; p.bias = bias; p.rowbias = rowbias; p.ldrb = ldrb;
   p.C = C; p.ldc = ldc; p.act = act; p.permT = permT; p.permA = permA;
-  p.wt = 0; p.wtap = 0; p.wcols = 0;
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0;
   dim3 grid((M + 127) / 128, (Npad + 127) / 128), block(256);
   if (dtype == MADIFF_BF16 && Cin % 64 == 0 && Csplit % 64 == 0 && use_dma_kernel())
     return madiff_launch_gemm_fwd_bf16(&p, out_f32, tile >= 0 ? tile : pick_tile(M, Npad, 0), stream);
@@ -416,13 +427,16 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
 // (gfx950 LDS-DMA kernel only; no transposed weight copy).  Requirements: bf16, Kred % 64 == 0 and every one of
 // the Kred rows of W is a real weight row; wcol0 % 8 == 0.  Returns 1 when the shape is not covered (the caller
 // then uses madiff_gemm_fwd on a transposed pack).
+// ksplit > 1: the reduction is cut into ksplit slices that combine with fp32 atomics; dX is then FP32 [M, ldx]
+// (zeroed here first).  For few-row, long-reduction shapes (the time-MLP bundle: 1024 x 256 output, K = 11520).
 extern "C" int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, int taps, int T_out, int T_in, int stride,
                                     int pad, int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad,
-                                    void* dX, int ldx, int tile, hipStream_t stream) {
+                                    void* dX, int ldx, int tile, int ksplit, hipStream_t stream) {
   if (M <= 0 || Ncols <= 0) return 0;
   if (!use_dma_kernel() || Kred % 64 || wcol0 % 8 || wtap % 8 || ldw % 8) return 1;
   if (check_rowmap(T_out, T_in, stride, pad, tr) || taps <= 0 || ldy < Kred || ldy % 8 || Npad < Ncols || ldx < Npad ||
-      wcol0 < 0 || wcol0 + Ncols > wtap || ldw < taps * wtap || M % T_out || tile >= 3)
+      wcol0 < 0 || wcol0 + Ncols > wtap || ldw < taps * wtap || M % T_out || tile >= kNumTiles ||
+      (tile >= 0 && kTileBN[tile] != 128))
     return -1;
   GemmFwdParams p;
   p.X = dY; p.ldx = ldy; p.X2 = nullptr; p.ldx2 = 0; p.Csplit = Kred;
@@ -432,16 +446,25 @@ extern "C" int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, in
   p.bias = nullptr; p.rowbias = nullptr; p.ldrb = 0;
   p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
   p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0;
+  const int nsteps = (Kred / 64) * taps;
+  p.ksplit = ksplit > 1 ? (ksplit < nsteps ? ksplit : nsteps) : 0;
+  if (p.ksplit > 1) {
+    hipError_t e = hipMemsetAsync(dX, 0, (size_t)M * ldx * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    return madiff_launch_gemm_fwd_bf16(&p, 1, 8, stream);       // 64x128, 3 stages, fp32 atomics
+  }
   return madiff_launch_gemm_fwd_bf16(&p, 0, tile >= 0 ? tile : pick_tile(M, Npad, 1), stream);
 }
 
 extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2,
                                  int ldx2, int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride,
-                                 int pad, int tr, float* dW, int ldw, int Nout, int accumulate, hipStream_t stream) {
+                                 int pad, int tr, float* dW, int ldw, int Nout, int accumulate, int tile, int splits,
+                                 hipStream_t stream) {
+  static const int kBO[4] = {128, 128, 64, 64}, kBC[4] = {128, 64, 128, 64};
   const int es = dtype == MADIFF_BF16 ? 2 : 4;
   if (M <= 0 || Nout <= 0) return 0;
   if (check_rowmap(T_out, T_in, stride, pad, tr) || Cin <= 0 || Cin % 32 || taps <= 0 || ldw < taps * Cin ||
-      Ycols % 32 || ldy < Ycols || (ldy * es) % 16 || (ldx * es) % 16 || M % T_out)
+      Ycols % 32 || ldy < Ycols || (ldy * es) % 16 || (ldx * es) % 16 || M % T_out || tile >= 4)
     return -1;
   if (X2 == nullptr) Csplit = Cin;
   if (Csplit > Cin || ldx < Csplit || (X2 && (Csplit % 128 || ldx2 < Cin - Csplit || (ldx2 * es) % 16))) return -1;
@@ -449,17 +472,22 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
   p.dY = dY; p.ldy = ldy; p.Ycols = Ycols; p.X = X; p.ldx = ldx; p.X2 = X2; p.ldx2 = ldx2; p.Csplit = Csplit;
   p.M = M; p.Cin = Cin; p.taps = taps; p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.dW = dW; p.ldw = ldw; p.Nout = Nout; p.accumulate = accumulate ? 1 : 0;
-  p.ctiles = (Cin + 127) / 128;
   const bool dma = dtype == MADIFF_BF16 && use_dma_kernel() && T_out < 256 && M < (1 << 24);
+  if (!dma || tile < 0) tile = 0;
+  const int BO = kBO[tile], BC = kBC[tile];
+  p.ctiles = (Cin + BC - 1) / BC;
   const int KR = dma ? 64 : (dtype == MADIFF_BF16 ? 32 : 16);
   int total_steps = (M + KR - 1) / KR;
-  int tiles = ((Nout + 127) / 128) * p.ctiles * taps;
-  // every extra split costs one more fp32 atomic pass over dW (atomics run at ~1.3 TB/s chip-wide), so only split
-  // the reduction as far as needed to put ~2 workgroups on each of the 256 CUs
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("MADIFF_WGRAD_BLOCKS"); target = e ? atoi(e) : 384; }
-  int splits = (target + tiles / 2) / tiles;
-  if (splits > total_steps / 4) splits = total_steps / 4 > 0 ? total_steps / 4 : 1;
+  int tiles = ((Nout + BO - 1) / BO) * p.ctiles * taps;
+  if (splits <= 0) {
+    // every extra split costs one more fp32 atomic pass over dW (atomics run at ~1.3 TB/s chip-wide), so only split
+    // the reduction as far as needed to put ~2 workgroups on each of the 256 CUs
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("MADIFF_WGRAD_BLOCKS"); target = e ? atoi(e) : 384; }
+    splits = (target + tiles / 2) / tiles;
+    if (splits > total_steps / 4) splits = total_steps / 4;
+  }
+  if (splits > total_steps) splits = total_steps;
   if (splits < 1) splits = 1;
   p.steps_per_split = (total_steps + splits - 1) / splits;
   p.splits = (total_steps + p.steps_per_split - 1) / p.steps_per_split;
@@ -467,8 +495,8 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
     hipError_t e = hipMemsetAsync(dW, 0, (size_t)Nout * ldw * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
   }
-  dim3 grid((Nout + 127) / 128, p.ctiles * taps, p.splits), block(256);
-  if (dma) return madiff_launch_gemm_wgrad_bf16(&p, grid.x, grid.y, grid.z, stream);
+  dim3 grid((Nout + BO - 1) / BO, p.ctiles * taps, p.splits), block(256);
+  if (dma) return madiff_launch_gemm_wgrad_bf16(&p, tile, grid.x, grid.y, grid.z, stream);
   if (dtype == MADIFF_BF16) hipLaunchKernelGGL((gemm_wgrad_kernel<bf16_t>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((gemm_wgrad_kernel<float>), grid, block, 0, stream, p);
   MADIFF_CHECK_LAUNCH();

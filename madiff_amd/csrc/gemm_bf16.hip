@@ -24,12 +24,22 @@ __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row
 //             B[k = (tap, o), n] = W[o*ldw + tap*wtap + n]; the B tile is [64 k][BN = 128 n] (256-byte rows, chunk swizzle
 //             wg_swz) and its fragments are read with the transposing ds_read_b64_tr_b16, exactly as the weight-gradient
 //             kernel reads its operands.  No transposed weight copy exists anywhere.
-template <typename OutT, int BM, int BN, bool WT>
+//
+// Pipeline: D LDS stages.  Step s waits (counted s_waitcnt vmcnt, never 0 in steady state) for its own DMA pieces of
+// stage s, passes ONE raw s_barrier (now every wave's pieces of stage s have landed and every wave has finished
+// reading stage s-1), re-issues stage s+D-1 into the buffer stage s-1 occupied, and multiplies stage s.  D-1 stages
+// of global_load_lds stay in flight across the barrier, which is what hides the L2/HBM latency when a CU holds only
+// one or two workgroups (small M).  All LDS lives in one __shared__ array and the loop contains no ordinary global
+// load, so hipcc adds no vmcnt(0) of its own.
+// Split-K: gridDim.z slices of the K-steps; slices combine with fp32 atomics (OutT = float, C pre-zeroed by the host).
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename OutT, int BM, int BN, bool WT, int D>
 __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) {
   static_assert(!WT || BN == 128, "the transposed-read image is laid out for 256-byte rows");
   constexpr int MI = BM / 32, NJ = BN / 32;          // 16x16 MFMA blocks per wave (rows, cols) = DMA pieces per wave
   constexpr int A_BYTES = BM * 128, BUF_BYTES = (BM + BN) * 128;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF_BYTES];   // [buf][A tile | W tile]
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[D * BUF_BYTES];   // [stage][A tile | W tile]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -66,7 +76,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
     }
   }
   const int spt = p.Cin >> 6;            // K-steps per tap
-  const int nsteps = spt * p.taps;
+  int s_lo = 0, nsteps = spt * p.taps;
+  if (p.ksplit > 1) {                    // this workgroup's slice of the K-steps
+    const int per = (nsteps + p.ksplit - 1) / p.ksplit;
+    s_lo = blockIdx.z * per;
+    nsteps = min(nsteps, s_lo + per) - s_lo;
+    if (nsteps <= 0) return;             // uniform for the workgroup
+  }
 
   int a_row[MI];
   auto tap_rows = [&](int tap) {
@@ -104,18 +120,28 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
   const int tq = fr >> 2, tp = fr & 3;
   typedef s16x4 __attribute__((address_space(3))) * lds_p;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  int tap = 0, cstep = 0;
-  tap_rows(0);
-  issue(0, 0, 0);
-  __syncthreads();
+  constexpr int PIECES = MI + WP;        // DMA instructions per wave per stage
+  int tap = s_lo / spt, cstep = s_lo - tap * spt;      // position of the NEXT stage to issue
+  tap_rows(tap);
+  int issued = 0, ibuf = 0;
+  auto issue_next = [&]() {
+    issue(ibuf, tap, cstep);
+    ++issued;
+    if (++ibuf == D) ibuf = 0;
+    if (++cstep == spt) { cstep = 0; ++tap; if (issued < nsteps) tap_rows(tap); }
+  };
+#pragma unroll
+  for (int d = 0; d < D - 1; d++)
+    if (d < nsteps) issue_next();
+  int buf = 0;
   for (int s = 0; s < nsteps; s++) {
-    const int buf = s & 1;
-    if (s + 1 < nsteps) {
-      if (++cstep == spt) { cstep = 0; ++tap; tap_rows(tap); }
-      issue(buf ^ 1, tap, cstep);
-    }
+    if (s + D - 1 <= nsteps) wait_vmcnt<(D - 2) * PIECES>();   // stage s landed, D-2 younger stages still in flight
+    else wait_vmcnt<0>();                                      // tail: fewer stages are outstanding
+    __builtin_amdgcn_s_barrier();
+    if (issued < nsteps) issue_next();                         // into the buffer every wave finished reading in step s-1
     const unsigned char* As = &smem[buf * BUF_BYTES];
     const unsigned char* Ws = As + A_BYTES;
+    if (++buf == D) buf = 0;
 #pragma unroll
     for (int kh = 0; kh < 2; kh++) {
       bf16x8 a[MI], b[NJ];
@@ -148,10 +174,82 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
         for (int j = 0; j < NJ; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();     // emits vmcnt(0): the DMA of step s+1 has landed, and every wave is done reading buf
   }
 
   OutT* C = (OutT*)p.C;
+  if (p.vec_epi) {
+    // Vector epilogue: each 16-row block of the wave tile goes through a wave-private fp32 LDS tile so that a lane
+    // owns 8 consecutive columns of one row: bias / row-bias / activation on vectors, one 16-byte store per lane
+    // (bf16) instead of eight 2-byte ones.  The host sets vec_epi only when every pointer / stride is 16-byte friendly.
+    constexpr int WN = BN / 2, LDT = WN + 4, VPR = WN / 8, RPP = 64 / VPR;
+    __syncthreads();                       // every wave is done with the operand tiles (no DMA is outstanding here)
+    float* stage = (float*)smem + wave * (16 * LDT);
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) stage[(fq * 4 + r) * LDT + j * 16 + fr] = acc[i][j][r];
+#pragma unroll
+      for (int pass = 0; pass < 16 / RPP; pass++) {
+        const int row = pass * RPP + lane / VPR, cv = lane % VPR;
+        const f32x4 v0 = *(const f32x4*)&stage[row * LDT + cv * 8];
+        const f32x4 v1 = *(const f32x4*)&stage[row * LDT + cv * 8 + 4];
+        const int m = m0 + wm * (BM / 2) + i * 16 + row;
+        const int n = n0 + wn * WN + cv * 8;
+        if (m >= p.M || n >= p.Npad) continue;
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int seq = m / p.rm.T_out;
+        size_t orow = m;
+        if (p.permA > 0) {
+          int t = m - seq * p.permT;
+          int b_ = seq / p.permA, a_ = seq - b_ * p.permA;
+          orow = ((size_t)b_ * p.permT + t) * p.permA + a_;
+        }
+        if (n + 8 <= p.Nout) {
+          if (p.bias) {
+            const f32x4 b0 = *(const f32x4*)&p.bias[n], b1 = *(const f32x4*)&p.bias[n + 4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+          }
+          if (p.rowbias) {
+            const float* rb = p.rowbias + (size_t)seq * p.ldrb + n;
+            const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+          }
+        } else {                              // the vector straddles / lies beyond the real columns: pad columns are 0
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            if (n + e < p.Nout) {
+              if (p.bias) v[e] += p.bias[n + e];
+              if (p.rowbias) v[e] += p.rowbias[(size_t)seq * p.ldrb + n + e];
+            } else {
+              v[e] = 0.f;
+            }
+          }
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = n + e < p.Nout ? mish_f(v[e]) : 0.f;
+        }
+        OutT* dst = C + orow * p.ldc + n;
+        if constexpr (sizeof(OutT) == 2) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; e++) o[e] = (bf16_t)v[e];
+          *(bf16x8*)dst = o;
+        } else {
+          *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+          *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MI; i++) {
 #pragma unroll
@@ -172,10 +270,15 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
         float v = 0.f;
         if (n < p.Nout) {
           v = acc[i][j][r];
-          if (p.bias) v += p.bias[n];
-          if (p.rowbias) v += p.rowbias[(size_t)seq * p.ldrb + n];
+          if (p.ksplit <= 1 || blockIdx.z == 0) {
+            if (p.bias) v += p.bias[n];
+            if (p.rowbias) v += p.rowbias[(size_t)seq * p.ldrb + n];
+          }
           if (p.act == 1) v = fmaxf(v, 0.f);
           else if (p.act == 2) v = mish_f(v);
+        }
+        if constexpr (sizeof(OutT) == 4) {
+          if (p.ksplit > 1) { if (n < p.Nout) atomicAdd((float*)&C[orow * p.ldc + n], v); continue; }
         }
         C[orow * p.ldc + n] = from_f32<OutT>(v);
       }
@@ -183,26 +286,37 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
   }
 }
 
-// Tile shapes the launcher can pick (index = the `tile` argument): the caller chooses per layer shape.
-//   0: 128x128   1: 96x128   2: 64x128   3: 128x64   4: 96x64   5: 64x64
+// Kernel variants the launcher can pick (index = the `tile` argument; the caller chooses per layer shape):
+//   id  0..5 : 128x128, 96x128, 64x128, 128x64, 96x64, 64x64 with 2 LDS stages
+//   id  6..11: the same shapes with 3 stages
+//   id 12, 13: 64x128 and 64x64 with 4 stages
+// WT kernels exist for the BN = 128 shapes only.
 template <typename OutT, bool WT>
 static int launch_tile(const GemmFwdParams& p, int tile, hipStream_t stream) {
-#define MADIFF_TILE(ID, BM_, BN_)                                                                                    \
+#define MADIFF_TILE(ID, BM_, BN_, D_)                                                                                \
   case ID: {                                                                                                         \
-    dim3 grid((p.M + BM_ - 1) / BM_, (p.Npad + BN_ - 1) / BN_);                                                       \
-    hipLaunchKernelGGL((gemm_fwd_bf16_kernel<OutT, BM_, BN_, WT>), grid, dim3(256), 0, stream, p);                    \
+    dim3 grid((p.M + BM_ - 1) / BM_, (p.Npad + BN_ - 1) / BN_, p.ksplit > 1 ? p.ksplit : 1);                          \
+    hipLaunchKernelGGL((gemm_fwd_bf16_kernel<OutT, BM_, BN_, WT, D_>), grid, dim3(256), 0, stream, p);                \
     break;                                                                                                           \
   }
   switch (tile) {
-    MADIFF_TILE(0, 128, 128)
-    MADIFF_TILE(1, 96, 128)
-    MADIFF_TILE(2, 64, 128)
+    MADIFF_TILE(0, 128, 128, 2)
+    MADIFF_TILE(1, 96, 128, 2)
+    MADIFF_TILE(2, 64, 128, 2)
+    MADIFF_TILE(6, 128, 128, 3)
+    MADIFF_TILE(7, 96, 128, 3)
+    MADIFF_TILE(8, 64, 128, 3)
+    MADIFF_TILE(12, 64, 128, 4)
     default:
       if constexpr (!WT) {
         switch (tile) {
-          MADIFF_TILE(3, 128, 64)
-          MADIFF_TILE(4, 96, 64)
-          MADIFF_TILE(5, 64, 64)
+          MADIFF_TILE(3, 128, 64, 2)
+          MADIFF_TILE(4, 96, 64, 2)
+          MADIFF_TILE(5, 64, 64, 2)
+          MADIFF_TILE(9, 128, 64, 3)
+          MADIFF_TILE(10, 96, 64, 3)
+          MADIFF_TILE(11, 64, 64, 3)
+          MADIFF_TILE(13, 64, 64, 4)
           default: return -1;
         }
       } else {
@@ -217,27 +331,53 @@ static int launch_tile(const GemmFwdParams& p, int tile, hipStream_t stream) {
 // launched from madiff_gemm_fwd / madiff_gemm_dgrad_wt (gemm.hip) when dtype == bf16 and Cin % 64 == 0 (and Csplit % 64 == 0)
 extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_fwd_bf16(const void* params, int out_f32, int tile,
                                                                                  hipStream_t stream) {
-  const GemmFwdParams& p = *(const GemmFwdParams*)params;
-  if (p.wt) return out_f32 ? -1 : launch_tile<bf16_t, true>(p, tile, stream);
+  GemmFwdParams p = *(const GemmFwdParams*)params;
+  {   // vector epilogue eligibility: 8-column vectors never straddle Npad, all rows / operands 16-byte aligned
+    const int es = out_f32 ? 4 : 2;
+    p.vec_epi = p.ksplit <= 1 && p.Npad % 8 == 0 && ((size_t)p.C % 16) == 0 && ((size_t)p.ldc * es) % 16 == 0 &&
+                (!p.bias || (size_t)p.bias % 16 == 0) &&
+                (!p.rowbias || ((size_t)p.rowbias % 16 == 0 && p.ldrb % 4 == 0));
+  }
+  if (p.wt && out_f32) {     // split-K data gradient: one variant, fp32 atomics
+    if (tile != 8) return -1;
+    dim3 grid((p.M + 63) / 64, (p.Npad + 127) / 128, p.ksplit > 1 ? p.ksplit : 1);
+    hipLaunchKernelGGL((gemm_fwd_bf16_kernel<float, 64, 128, true, 3>), grid, dim3(256), 0, stream, p);
+    MADIFF_CHECK_LAUNCH();
+    return 0;
+  }
+  if (p.wt) return launch_tile<bf16_t, true>(p, tile, stream);
   return out_f32 ? launch_tile<float, false>(p, tile, stream) : launch_tile<bf16_t, false>(p, tile, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight gradient, bf16: dW[o, tap*Cin + c] = sum_m dY[m, o] * X[src(m, tap), c]
+// weight gradient, bf16: dW[o, tap*Cin + c] (+)= sum_m dY[m, o] * X[src(m, tap), c]
 // Same LDS-DMA structure.  Both operands arrive with the REDUCTION index (m) as the row, so the MFMA fragments
 // (8 consecutive reduction elements per lane) are read with ds_read_b64_tr_b16, the hardware transposing LDS read.
-// Tiles are [64 reduction rows][128 columns] bf16 = 256-byte rows; chunk swizzle of a row:
-//   ch ^= ((row & 3) << 2) | ((row >> 2) & 3)     (conflict-free for the transposed reads of a 16x16x32 operand)
-// applied on the DMA source side and on the read side.
+// Output tile BO x BC (each 64 or 128), 4 waves as 2 x 2; operand tiles are [64 reduction rows][BO or BC columns]:
+//   128 columns = 256-byte rows of 16 chunks, chunk swizzle  ch ^= ((row & 3) << 2) | ((row >> 2) & 3)
+//    64 columns = 128-byte rows of  8 chunks, chunk swizzle  ch ^= (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1
+// (both conflict-free for the transposed reads of a 16x16x32 operand: the 8 rows a half-wave touches land on 8
+// different 32-byte bank slots), applied on the DMA source side and on the read side.
 // ------------------------------------------------------------------------------------------------
+template <int COLS> __device__ __forceinline__ int tr_swz(int row) {
+  if constexpr (COLS == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
+  else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
+}
+
+template <int BO, int BC>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams p, unsigned magic) {
   constexpr int KR = 64;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2][32768];   // [buf][dY tile 16 KB | X tile 16 KB]
+  constexpr int MI = BO / 32, NJ = BC / 32;
+  constexpr int Y_BYTES = KR * BO * 2, X_BYTES = KR * BC * 2, BUF_BYTES = Y_BYTES + X_BYTES;
+  constexpr int YCH = BO / 8, XCH = BC / 8;              // 16-byte chunks per tile row
+  constexpr int YP = YCH / 4, XP = XCH / 4;              // DMA pieces (1 KB) per wave: wave w fills rows [16w, 16w+16)
+  constexpr int YRP = 64 / YCH, XRP = 64 / XCH;          // rows per piece
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF_BYTES];   // [buf][dY tile | X tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wc = wave & 1;
-  const int n0 = blockIdx.x * 128;
+  const int n0 = blockIdx.x * BO;
   const int tap = blockIdx.y / p.ctiles;
-  const int c0 = (blockIdx.y - tap * p.ctiles) * 128;
+  const int c0 = (blockIdx.y - tap * p.ctiles) * BC;
   const int total_steps = (p.M + KR - 1) / KR;
   const int s_begin = blockIdx.z * p.steps_per_split;
   int s_end = s_begin + p.steps_per_split;
@@ -248,44 +388,49 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
   int ldx = p.ldx, cx = c0, cmax = p.Csplit;
   if (c0 >= p.Csplit) { xsrc = (const unsigned char*)p.X2; ldx = p.ldx2; cx = c0 - p.Csplit; cmax = p.Cin - p.Csplit; }
 
-  // DMA slots: one wave instruction = 4 rows x 16 chunks.  Wave w fills rows [16w, 16w+16) of both tiles.
-  const int pos = lane & 15;
-  int srow[4], ych[4], xch[4];
-  bool yok[4], xok[4];
+  int yrow[YP], ych[YP], xrow[XP], xch[XP];
+  bool yok[YP], xok[XP];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    srow[j] = 16 * wave + 4 * j + (lane >> 4);
-    int ch = pos ^ wg_swz(srow[j]);
-    ych[j] = ch; xch[j] = ch;
-    yok[j] = n0 + ch * 8 < p.Ycols;
-    xok[j] = cx + ch * 8 < cmax;
+  for (int j = 0; j < YP; j++) {
+    yrow[j] = 16 * wave + YRP * j + lane / YCH;
+    ych[j] = (lane % YCH) ^ tr_swz<BO>(yrow[j]);
+    yok[j] = n0 + ych[j] * 8 < p.Ycols;
+  }
+#pragma unroll
+  for (int j = 0; j < XP; j++) {
+    xrow[j] = 16 * wave + XRP * j + lane / XCH;
+    xch[j] = (lane % XCH) ^ tr_swz<BC>(xrow[j]);
+    xok[j] = cx + xch[j] * 8 < cmax;
   }
   const unsigned char* zero = g_zero_page + (lane & 15) * 16;
 
   auto issue = [&](int buf, int s) {
+    unsigned char* base = &smem[buf * BUF_BYTES];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      int m = s * KR + srow[j];
+    for (int j = 0; j < YP; j++) {
+      int m = s * KR + yrow[j];
       const unsigned char* gy = zero;
+      if (m < p.M && yok[j]) gy = (const unsigned char*)p.dY + ((size_t)m * p.ldy + n0 + ych[j] * 8) * 2;
+      __builtin_amdgcn_global_load_lds((gptr_t)gy, (lptr_t)(base + (YP * wave + j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+      int m = s * KR + xrow[j];
       const unsigned char* gx = zero;
-      if (m < p.M) {
-        if (yok[j]) gy = (const unsigned char*)p.dY + ((size_t)m * p.ldy + n0 + ych[j] * 8) * 2;
-        if (xok[j]) {
-          int n = magic ? (int)__umulhi((unsigned)m, magic) : m;   // magic == 0 <=> T_out == 1
-          int r = map_row(n, m - n * p.rm.T_out, tap, p.rm);
-          if (r >= 0) gx = xsrc + ((size_t)r * ldx + cx + xch[j] * 8) * 2;
-        }
+      if (m < p.M && xok[j]) {
+        int n = magic ? (int)__umulhi((unsigned)m, magic) : m;   // magic == 0 <=> T_out == 1
+        int r = map_row(n, m - n * p.rm.T_out, tap, p.rm);
+        if (r >= 0) gx = xsrc + ((size_t)r * ldx + cx + xch[j] * 8) * 2;
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)gy, (lptr_t)&smem[buf][(4 * wave + j) * 1024], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)gx, (lptr_t)&smem[buf][16384 + (4 * wave + j) * 1024], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gx, (lptr_t)(base + Y_BYTES + (XP * wave + j) * 1024), 16, 0, 0);
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < MI; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
   const int tq = fr >> 2, tp = fr & 3;
@@ -296,42 +441,45 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
   for (int s = s_begin; s < s_end; s++) {
     const int buf = (s - s_begin) & 1;
     if (s + 1 < s_end) issue(buf ^ 1, s + 1);
-    const unsigned char* Ys = &smem[buf][0];
-    const unsigned char* Xs = &smem[buf][16384];
+    const unsigned char* Ys = &smem[buf * BUF_BYTES];
+    const unsigned char* Xs = Ys + Y_BYTES;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
-      bf16x8 a[4], b[4];
+      bf16x8 a[MI], b[NJ];
       const int r0 = 32 * kb + 8 * fq + tq, r1 = r0 + 4;
-      const int z0 = wg_swz(r0), z1 = wg_swz(r1);
+      const int o = 8 * (tp & 1);
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int ca = 8 * wn + 2 * i + (tp >> 1), cb = 8 * wc + 2 * i + (tp >> 1);
-        const int o = 8 * (tp & 1);
-        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Ys + r0 * 256 + ((ca ^ z0) << 4) + o));
-        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Ys + r1 * 256 + ((ca ^ z1) << 4) + o));
-        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Xs + r0 * 256 + ((cb ^ z0) << 4) + o));
-        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Xs + r1 * 256 + ((cb ^ z1) << 4) + o));
+      for (int i = 0; i < MI; i++) {
+        const int ca = (YCH / 2) * wn + 2 * i + (tp >> 1);
+        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Ys + r0 * (BO * 2) + ((ca ^ tr_swz<BO>(r0)) << 4) + o));
+        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Ys + r1 * (BO * 2) + ((ca ^ tr_swz<BO>(r1)) << 4) + o));
         a[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-        b[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int j = 0; j < NJ; j++) {
+        const int cb = (XCH / 2) * wc + 2 * j + (tp >> 1);
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Xs + r0 * (BC * 2) + ((cb ^ tr_swz<BC>(r0)) << 4) + o));
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Xs + r1 * (BC * 2) + ((cb ^ tr_swz<BC>(r1)) << 4) + o));
+        b[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      int n = n0 + wn * 64 + i * 16 + fq * 4 + r;
+      int n = n0 + wn * (BO / 2) + i * 16 + fq * 4 + r;
       if (n >= p.Nout) continue;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        int c = c0 + wc * 64 + j * 16 + fr;
+      for (int j = 0; j < NJ; j++) {
+        int c = c0 + wc * (BC / 2) + j * 16 + fr;
         if (c >= p.Cin) continue;
         float* dst = p.dW + (size_t)n * p.ldw + (size_t)tap * p.Cin + c;
         if (p.splits > 1) atomicAdd(dst, acc[i][j][r]);
@@ -341,13 +489,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
     }
 }
 
-// KR = 64 reduction rows per step here (the generic kernel uses 32): the caller sizes steps_per_split for 64.
-extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_wgrad_bf16(const void* params, int gx, int gy, int gz,
-                                                                                   hipStream_t stream) {
+// tile: 0 = 128x128, 1 = 128x64 (O x C), 2 = 64x128, 3 = 64x64.  KR = 64 reduction rows per step (the generic kernel
+// uses 32): the caller sizes steps_per_split for 64 and the grid for the tile.
+extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_wgrad_bf16(const void* params, int tile, int gx, int gy,
+                                                                                   int gz, hipStream_t stream) {
   GemmWgradParams p = *(const GemmWgradParams*)params;
   unsigned d = (unsigned)p.rm.T_out;
   unsigned magic = d == 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d);
-  hipLaunchKernelGGL(gemm_wgrad_bf16_kernel, dim3(gx, gy, gz), dim3(256), 0, stream, p, magic);
+  dim3 grid(gx, gy, gz);
+  switch (tile) {
+    case 0: hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, stream, p, magic); break;
+    case 1: hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<128, 64>), grid, dim3(256), 0, stream, p, magic); break;
+    case 2: hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<64, 128>), grid, dim3(256), 0, stream, p, magic); break;
+    case 3: hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<64, 64>), grid, dim3(256), 0, stream, p, magic); break;
+    default: return -1;
+  }
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

@@ -24,6 +24,8 @@ struct GemmFwdParams {
   // wt = 1 (data gradient straight from the FORWARD weight layout, bf16 LDS-DMA kernel only):
   //   B[k = (tap, o), n] = W[o * ldw + tap * wtap + n], n < wcols valid columns
   int wt, wtap, wcols;
+  int vec_epi;                       // 1: pointers/strides allow the 16-byte vector epilogue (set by the launcher)
+  int ksplit;                        // > 1: gridDim.z slices of the K-steps combine with fp32 atomics (fp32 C, pre-zeroed)
 };
 
 struct GemmWgradParams {

@@ -21,8 +21,10 @@ _SIGS = {
     "madiff_gemm_fwd": [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i,
                         _vp, _i, _i, _i, _i, _i, _vp],
     "madiff_gemm_tile_count": [],
-    "madiff_gemm_dgrad_wt": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
-    "madiff_gemm_wgrad": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "madiff_gemm_tile_info": [_i, _vp, _vp, _vp],
+    "madiff_gemm_dgrad_wt": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "madiff_gemm_wgrad": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i,
+                          _vp],
     "madiff_pack_weight": [_i, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
     "madiff_pack_weights_multi": [_i, _vp, _i, _i, _vp],
     "madiff_gn_mish_fwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _i, _vp],
@@ -84,6 +86,18 @@ def call_rc(name: str, *args) -> int:
 
 def tile_count() -> int:
     return _lib.madiff_gemm_tile_count()
+
+
+def tiles(wt: bool = False):
+    """Variant ids of the LDS-DMA GEMM (wt=True: those the transposed-weight data-gradient kernel offers)."""
+    n = _lib.madiff_gemm_tile_count()
+    return [t for t in range(n) if not wt or _lib.madiff_gemm_tile_info(t, None, None, None) == 1]
+
+
+def tile_info(tile: int):
+    bm, bn, d = C.c_int(), C.c_int(), C.c_int()
+    rc = _lib.madiff_gemm_tile_info(tile, C.byref(bm), C.byref(bn), C.byref(d))
+    return bm.value, bn.value, d.value, rc == 1
 
 
 def exported(name: str) -> bool:

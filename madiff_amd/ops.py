@@ -262,7 +262,7 @@ _TUNE: dict = {}
 _AUTOTUNE = os.environ.get("MADIFF_AUTOTUNE", "1") != "0"
 
 
-def _tuned_tile(sig, n_tiles: int, launch) -> int:
+def _tuned_tile(sig, candidates, launch) -> int:
     """Output tile of the LDS-DMA GEMM for one layer shape.  The first time a shape is seen (outside graph capture)
     every tile the library offers is timed on the real operands and the fastest is remembered; results do not depend
     on the tile (same reduction order per output element), so this is a pure speed choice.  -1 = library's model."""
@@ -272,7 +272,7 @@ def _tuned_tile(sig, n_tiles: int, launch) -> int:
     if not _AUTOTUNE or _PRECISION != "bf16" or torch.cuda.is_current_stream_capturing():
         return -1
     best, best_ms = -1, float("inf")
-    for tile in range(n_tiles):
+    for tile in candidates:
         launch(tile)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -299,35 +299,76 @@ def _gemm(x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, tr, W, nout, npad,
                  perm[0] if perm else 0, perm[1] if perm else 0, tile, _stream())
 
     tile = _tuned_tile(("fwd", M, cin, spec.taps, npad, t_out, spec.stride, tr, out_f32, x2 is not None),
-                       lib.tile_count(), launch) if dma else -1
+                       lib.tiles(), launch) if dma else -1
     launch(tile)
 
 
-def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncols, gx) -> bool:
-    """Data gradient straight from the forward-layout bf16 weights (no transposed pack).  False: shape not covered."""
+def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncols, ncols_pad):
+    """Data gradient straight from the forward-layout bf16 weights (no transposed pack).  Returns the cl gradient
+    [M_in, ncols_pad], or None when the shape is not covered."""
+    # few output tiles + a long reduction (the time-MLP bundle: 1024 x 256 from K = 11520): slice the reduction
+    blocks = -(-M_in // 64) * -(-ncols_pad // 128)
+    nsteps = (npad // 64) * spec.taps
+    ksplit = 0
+    if blocks < 96 and nsteps >= 32:
+        ksplit = max(1, min(nsteps // 8, 256 // blocks))
+    gx = torch.empty(M_in, ncols_pad, dtype=torch.float32 if ksplit > 1 else act_dtype(), device=dy.device)
+
     def launch(tile):
         return lib.call_rc("madiff_gemm_dgrad_wt", dy.data_ptr(), dy.stride(0), M_in, npad, spec.taps, t_in, t_out,
                            spec.stride, spec.pad, 1 - spec.tr, Wf.data_ptr(), Wf.stride(0), wtap, wcol0, ncols,
-                           gx.shape[1], gx.data_ptr(), gx.stride(0), tile, _stream())
+                           ncols_pad, gx.data_ptr(), gx.stride(0), tile, ksplit, _stream())
 
-    sig = ("wt", M_in, npad, spec.taps, gx.shape[1], t_in, spec.stride, spec.tr)
+    sig = ("wt", M_in, npad, spec.taps, ncols_pad, t_in, spec.stride, spec.tr)
     tile = _TUNE.get(sig)
-    if tile is None:
-        if launch(-1) != 0:          # probe = the real launch with the library's default tile
-            _TUNE[sig] = "uncovered"
-            return False
-        _tuned_tile(sig, 3, launch)  # remembers the fastest tile for the next call (no-op under capture / when disabled)
-        return True
     if tile == "uncovered":
-        return False
-    launch(tile)
-    return True
+        return None
+    if ksplit > 1 or tile is None:
+        if launch(-1) != 0:          # probe = the real launch with the library's default variant
+            _TUNE[sig] = "uncovered"
+            return None
+        if ksplit <= 1:
+            _tuned_tile(sig, lib.tiles(wt=True), launch)   # remember the fastest variant (no-op under capture / if disabled)
+    else:
+        launch(tile)
+    return gx.to(act_dtype()) if ksplit > 1 else gx
+
+
+_WGRAD_TILES = ((128, 128), (128, 64), (64, 128), (64, 64))      # (O, C) output tiles of gemm_wgrad_bf16_kernel
 
 
 def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, accumulate=0):
-    lib.call("madiff_gemm_wgrad", _dt(), dy.data_ptr(), dy.stride(0), dy.shape[1], x.data_ptr(), x.stride(0), _p(x2),
-             0 if x2 is None else x2.stride(0), csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad, spec.tr,
-             dW.data_ptr(), dW.stride(0), nout, accumulate, _stream())
+    def launch(dst, acc, tile, splits):
+        lib.call("madiff_gemm_wgrad", _dt(), dy.data_ptr(), dy.stride(0), dy.shape[1], x.data_ptr(), x.stride(0), _p(x2),
+                 0 if x2 is None else x2.stride(0), csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad,
+                 spec.tr, dst.data_ptr(), dst.stride(0), nout, acc, tile, splits, _stream())
+
+    sig = ("wgrad", M, cin, spec.taps, nout, t_out, spec.stride, spec.tr, x2 is not None, accumulate)
+    cfg = _TUNE.get(sig)
+    if cfg is None and _AUTOTUNE and _PRECISION == "bf16" and not torch.cuda.is_current_stream_capturing():
+        # time every (tile, reduction split) candidate on the real operands into a scratch matrix
+        scratch = torch.empty(nout, dW.shape[1], dtype=torch.float32, device=dW.device)
+        steps = (M + 63) // 64
+        best, best_ms = (-1, 0), float("inf")
+        for tile, (bo, bc) in enumerate(_WGRAD_TILES):
+            tiles = -(-nout // bo) * -(-cin // bc) * spec.taps
+            for splits in (1, 2, 3, 4, 6, 8):
+                if splits > 1 and (splits > steps // 4 or tiles * splits > 4096):
+                    continue
+                launch(scratch, 1, tile, splits)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    launch(scratch, 1, tile, splits)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if ms < best_ms:
+                    best, best_ms = (tile, splits), ms
+        cfg = _TUNE[sig] = best
+    if cfg is None:
+        cfg = (-1, 0)
+    launch(dW, accumulate, cfg[0], cfg[1])
 
 
 def pack_traj(x: torch.Tensor, fpad: int, noise=None, t=None, sqrt_ac=None, sqrt_1mac=None, cond=None, mask=None,
@@ -539,15 +580,16 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
             if not need:
                 grads.append(None)
                 continue
-            gx = torch.empty(M_in, pad32(rows), dtype=act_dtype(), device=dy.device)
-            done = [False]
+            res = [None]
 
             def run_wt():
-                done[0] = _dgrad_wt(dy, M_in, npad, spec, t_in, t_out, Wf, cin, row0, rows, gx)
+                res[0] = _dgrad_wt(dy, M_in, npad, spec, t_in, t_out, Wf, cin, row0, rows, pad32(rows))
 
             if Wf is not None:
                 _timed("gemm_fwd_bf16_kernel", g.flops * rows / I, run_wt)
-            if not done[0]:
+            gx = res[0]
+            if gx is None:
+                gx = torch.empty(M_in, pad32(rows), dtype=act_dtype(), device=dy.device)
                 if Wb is None:
                     Wb = _packed(weights, spec, True)          # [I, taps * npad]
                 es = Wb.element_size()

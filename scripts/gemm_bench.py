@@ -18,7 +18,8 @@ shapes = [("T2 1024->1024 k5", 6, 1024, 1024, ops.CONV5, 7), ("T2 2048->512 k5",
           ("T2 512->1024 1x1", 6, 512, 1024, ops.CONV1, 1), ("T2 2048->512 1x1", 6, 2048, 512, ops.CONV1, 1),
           ("T1 128->512 1x1", 12, 128, 512, ops.CONV1, 1), ("T1 1024->128 1x1", 12, 1024, 128, ops.CONV1, 1)]
 tot = [0.0, 0.0, 0.0]
-TILES = ["128x128", "96x128", "64x128", "128x64", "96x64", "64x64"]
+TILES = ["%dx%d/%d" % ops.lib.tile_info(t)[:3] for t in range(ops.lib.tile_count())]
+WT_TILES = ops.lib.tiles(wt=True)
 
 
 def timeit(fn, n=20):
@@ -45,23 +46,35 @@ for name, T, ci, co, spec, cnt in shapes:
     flops = 2.0 * M * ci * co * spec.taps
     st = ops._stream()
     fw = []
-    for tile in range(6):
+    for tile in range(len(TILES)):
         fw.append(timeit(lambda: ops.lib.call("madiff_gemm_fwd", 1, 0, x.data_ptr(), ci, None, 0, ci, M, ci, spec.taps, T, T,
                                               1, spec.pad, 0, Wf.data_ptr(), Wf.stride(0), co, co, None, None, 0,
                                               y.data_ptr(), co, 0, 0, 0, tile, st)))
     dg = []
-    for tile in range(3):
+    for tile in WT_TILES:
         dg.append(timeit(lambda: ops.lib.call_rc("madiff_gemm_dgrad_wt", gy.data_ptr(), co, M, co, spec.taps, T, T, 1,
                                                  spec.pad, 1, Wf.data_ptr(), Wf.stride(0), ci, 0, ci, ci, dx.data_ptr(),
-                                                 ci, tile, st)))
-    dW = torch.empty(co, spec.taps * ci, dtype=torch.float32, device=dev)
-    tw = timeit(lambda: ops._wgrad(gy, x, None, ci, M, ci, spec, T, T, dW, co))
+                                                 ci, tile, 0, st)))
+    dW = torch.zeros(co, spec.taps * ci, dtype=torch.float32, device=dev)
+    wg = {}
+    steps = (M + 63) // 64
+    for tile, (bo, bc) in enumerate(ops._WGRAD_TILES):
+        for splits in (1, 2, 3, 4, 6, 8):
+            if splits > 1 and (splits > steps // 4 or (co // bo) * (ci // bc) * spec.taps * splits > 4096):
+                continue
+            wg[(tile, splits)] = timeit(lambda: ops.lib.call(
+                "madiff_gemm_wgrad", 1, gy.data_ptr(), co, co, x.data_ptr(), ci, None, 0, ci, M, ci, spec.taps, T, T, 1,
+                spec.pad, 0, dW.data_ptr(), dW.stride(0), co, 1, tile, splits, st), n=10)
+    kbest = min(wg, key=wg.get)
+    tw = wg[kbest]
+    wdesc = " ".join(f"{t}/{sp}:{flops / v / 1e9:.0f}" for (t, sp), v in wg.items())
     tot[0] += cnt * min(fw)
     tot[1] += cnt * min(dg)
     tot[2] += cnt * tw
     f = " ".join(f"{flops / t / 1e9:6.0f}" for t in fw)
     d = " ".join(f"{flops / t / 1e9:6.0f}" for t in dg)
-    print(f"{name:20s} x{cnt} fwd TF [{f}] best {TILES[fw.index(min(fw))]:>7s} {min(fw) * 1e3:6.1f} us | dgrad_wt TF [{d}] "
-          f"{min(dg) * 1e3:6.1f} us | wgrad {tw * 1e3:6.1f} us {flops / tw / 1e9:6.0f} TF", flush=True)
+    print(f"{name:20s} x{cnt} fwd TF [{f}] best {TILES[fw.index(min(fw))]:>9s} {min(fw) * 1e3:6.1f} us | dgrad_wt TF [{d}] best {TILES[WT_TILES[dg.index(min(dg))]]:>9s} "
+          f"{min(dg) * 1e3:6.1f} us | wgrad best tile/splits {kbest} {tw * 1e3:6.1f} us {flops / tw / 1e9:6.0f} TF", flush=True)
+    print("      wgrad TF by tile/splits:", wdesc, flush=True)
 print("tiles:", TILES)
 print(f"weighted totals per step (ms): fwd {tot[0]:.3f} dgrad {tot[1]:.3f} wgrad {tot[2]:.3f}")

@@ -103,7 +103,7 @@ def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
         F.conv_transpose1d(x, w, None, stride=spec.stride, padding=spec.pad)
     T2 = spec.out_len(T)
     gy = _q(_rand(*ref.shape, seed=3), "bf16").to(dev)
-    (gx_ref,) = torch.autograd.grad(ref, [x], gy)
+    gx_ref, gw_ref = torch.autograd.grad(ref, [x, w], gy)
     xcl = M.to_cl(x.detach())
     Wf = ops._packed([w.detach()], spec, False)
     st = torch.cuda.current_stream().cuda_stream
@@ -118,14 +118,32 @@ def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
         assert torch.equal(y, outs[0]), f"tile {tile} differs from tile 0"
     gycl = M.to_cl(gy)
     gxs = []
-    for tile in range(3):
+    for tile in lib.tiles(wt=True):
         gx = torch.full((N * T, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
         rc = lib.call_rc("madiff_gemm_dgrad_wt", gycl.data_ptr(), gycl.stride(0), N * T, Co, k, T, T2, spec.stride,
-                         spec.pad, 1 - spec.tr, Wf.data_ptr(), Wf.stride(0), Cin, 0, Cin, Cin, gx.data_ptr(), Cin, tile, st)
+                         spec.pad, 1 - spec.tr, Wf.data_ptr(), Wf.stride(0), Cin, 0, Cin, Cin, gx.data_ptr(), Cin, tile, 0,
+                         st)
         assert rc == 0
         gxs.append(gx)
         assert rel_err(M.from_cl(gx, N, T, Cin).cpu(), gx_ref.cpu()) < 3 * TOL["bf16"], tile
         assert torch.equal(gx, gxs[0])
+    # sliced reduction (fp32 atomics, fp32 output)
+    gx32 = torch.full((N * T, Cin), float("nan"), dtype=torch.float32, device=dev)
+    rc = lib.call_rc("madiff_gemm_dgrad_wt", gycl.data_ptr(), gycl.stride(0), N * T, Co, k, T, T2, spec.stride, spec.pad,
+                     1 - spec.tr, Wf.data_ptr(), Wf.stride(0), Cin, 0, Cin, Cin, gx32.data_ptr(), Cin, -1, 3, st)
+    assert rc == 0
+    assert rel_err(M.from_cl(gx32, N, T, Cin).cpu(), gx_ref.cpu()) < 3 * TOL["bf16"]
+    # weight gradient: every (O x C) tile and several reduction splits, overwrite and accumulate modes
+    gw_ref = gw_ref.permute(0, 2, 1) if spec.kind == "conv" else gw_ref.permute(1, 2, 0)        # -> [O, taps, I]
+    for tile in range(4):
+        for splits in (1, 3):
+            for accumulate in (0, 1):
+                dW = torch.full((Co, k * Cin), 1.0 if accumulate else float("nan"), dtype=torch.float32, device=dev)
+                lib.call("madiff_gemm_wgrad", lib.BF16, gycl.data_ptr(), gycl.stride(0), gycl.shape[1], xcl.data_ptr(),
+                         xcl.stride(0), None, 0, Cin, N * T2, Cin, k, T2, T, spec.stride, spec.pad, spec.tr,
+                         dW.data_ptr(), dW.stride(0), Co, accumulate, tile, splits, st)
+                got = dW.view(Co, k, Cin) - (1.0 if accumulate else 0.0)
+                assert rel_err(got.cpu(), gw_ref.cpu()) < 3 * TOL["bf16"], (tile, splits, accumulate)
 
 
 def test_conv_gemm_split_source(prec):
