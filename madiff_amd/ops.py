@@ -168,6 +168,12 @@ def _refresh_stale(trigger_key):
             rows.append(list(j) + [n, blk])
             blk += (n + PACK_EPB - 1) // PACK_EPB
     sig = tuple(tuple(r) for r in rows)
+    if _MULTI["sig"] != sig and torch.cuda.is_current_stream_capturing():
+        for key, ent, ws, v in stale:          # no host-to-device table upload inside a capture: one launch per job
+            for j in ent.jobs(ws):
+                lib.call("madiff_pack_weight", _dt(), j[0], j[1], j[2], j[3], j[4], j[5], j[6], j[7], j[8], j[9], _stream())
+            ent.vers = v
+        return
     if _MULTI["sig"] != sig:
         dev = stale[0][1].buf.device
         _MULTI["table"] = torch.tensor(rows, dtype=torch.int64).to(dev)

@@ -216,8 +216,10 @@ class FlatAdamEMA:
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 
-    def step(self, do_ema: int = 0):
-        """do_ema: 0 none, 1 lerp with ema_decay, 2 copy (reference: before step_start_ema)."""
+    def step(self, do_ema: int = 0, device_state: Optional[torch.Tensor] = None):
+        """do_ema: 0 none, 1 lerp with ema_decay, 2 copy (reference: before step_start_ema).
+        device_state (int32[2] on the GPU = {completed steps, do_ema}): the bias corrections and the EMA mode are taken
+        from the device instead of the arguments, so the launch can live inside a replayed hipGraph (GraphedTrainStep)."""
         first = self.flat_p is None
         if first:
             self._materialise()
@@ -232,7 +234,8 @@ class FlatAdamEMA:
         if self.use_hip:
             lib.call("madiff_adam_ema", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                      self.flat_v.data_ptr(), None if self.flat_ema is None else self.flat_ema.data_ptr(), self.total,
-                     self.lr, b1, b2, self.eps, bc1, bc2s, scale, do_ema, self.ema_decay, None,
+                     self.lr, b1, b2, self.eps, bc1, bc2s, scale, do_ema, self.ema_decay,
+                     None if device_state is None else device_state.data_ptr(),
                      self.flat_p16.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
             self._grads_zeroed = True
             ops.params_changed(by_optimizer=True)
@@ -272,3 +275,89 @@ def train_step(diffusion, opt: FlatAdamEMA, batches, do_ema: int = 0):
     opt.step(do_ema)
     opt.zero_grad()
     return out
+
+
+class GraphedTrainStep:
+    """One optimizer step (loss forward, backward, fused Adam/EMA) captured ONCE into a hipGraph and replayed: the
+    ~340 kernel launches of a step then cost one host call, which matters because at batch 256 the GPU finishes a
+    step faster than Python can issue it.  Same arithmetic as train_step: the graph holds exactly the launches an eager
+    step makes.  What changes per step lives in static device buffers refreshed before each replay:
+      * the batch (copied into the captured input tensors),
+      * the classifier-free-guidance dropout mask, drawn like the reference on the CPU generator
+        (ma_temporal.py:346-351) and copied over,
+      * {completed steps, EMA mode} for the Adam kernel's bias corrections (device int32[2]).
+    The diffusion timestep t and the noise are drawn inside the graph by torch's graph-safe Philox generator, in the
+    reference's order.  Single-process only (world_size 1): the data-parallel path keeps the eager, overlapped step.
+    Call after at least one eager train_step (buffers materialised, GEMM variants tuned)."""
+
+    def __init__(self, diffusion, opt: FlatAdamEMA, example_batch: dict, draws: Optional[dict] = None):
+        """draws = {"t", "noise", "dropout_mask"} fixes the random draws of every replay (parity tests)."""
+        assert opt.world == 1 and opt.flat_p is not None and opt.use_hip
+        self.draws = None if draws is None else {k: v.clone() for k, v in draws.items()}
+        self.diffusion, self.opt = diffusion, opt
+        clone = lambda v: {k: clone(u) for k, u in v.items()} if isinstance(v, dict) else v.clone()  # noqa: E731
+        self.batch = clone(example_batch)
+        dev = opt.flat_p.device
+        net = diffusion.model
+        self.mask_dist = net.net.mask_dist if getattr(net, "returns_condition", False) else None
+        B = example_batch["x"].shape[0]
+        self.mask = torch.ones(B, net.n_agents, 1, device=dev)
+        if self.draws is not None:
+            self.mask_dist = None
+            self.mask.copy_(self.draws["dropout_mask"].reshape(self.mask.shape))
+        # host staging for the per-step mask: a ring of pinned buffers, each guarded by an event, because the host runs
+        # several replays ahead of the GPU and must not overwrite a buffer whose async copy has not executed yet
+        self._ring = [(torch.ones(B, net.n_agents, 1).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+        self._ring_pos = 0
+        self.state = torch.tensor([opt.step_count, 0], dtype=torch.int32, device=dev)   # {completed steps, EMA mode}
+        assert ops.TIMER is None, "per-launch event timing cannot be captured"
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # one more eager step on the capture stream (allocator / autograd warm-up)
+            self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.infos = self._body(captured=True)
+        # the step counter lives on the device from here on: the captured Adam launch reads it and a captured
+        # one-thread kernel increments it after every replay
+        self.state.copy_(torch.tensor([opt.step_count, 0], dtype=torch.int32))
+
+    def _body(self, captured: bool = False):
+        extra = {} if self.draws is None else {"t": self.draws["t"], "noise": self.draws["noise"]}
+        loss, infos = self.diffusion.loss(**self.batch, dropout_mask=self.mask, **extra)
+        loss.backward()
+        if captured:
+            self.opt.step(device_state=self.state)      # launches only; host-side counters advance in step()
+            self.opt.step_count -= 1
+        else:
+            self.opt.step(0)
+        self.opt.zero_grad()
+        return loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in infos.items()}
+
+    def _copy_in(self, dst, src):
+        if isinstance(dst, dict):
+            for k in dst:
+                self._copy_in(dst[k], src[k])
+        elif dst.data_ptr() != src.data_ptr():
+            dst.copy_(src, non_blocking=True)
+
+    def step(self, batch: Optional[dict] = None, do_ema: int = 0):
+        """Replays the captured step on `batch` (None: the batch already in the static buffers)."""
+        if batch is not None:
+            self._copy_in(self.batch, batch)
+        if self.mask_dist is not None:
+            host, ev = self._ring[self._ring_pos]
+            self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+            ev.synchronize()
+            host.copy_(self.mask_dist.sample(sample_shape=tuple(host.shape[:2]) + (1,)).reshape(host.shape))
+            self.mask.copy_(host, non_blocking=True)
+            ev.record()
+        if self.opt.ema_module is None:
+            do_ema = 0
+        self.state[1:].fill_(int(do_ema))      # the value travels as a kernel argument: no host buffer to race on
+        self.graph.replay()
+        self.opt.step_count += 1
+        ops.params_changed(by_optimizer=True)
+        return self.loss, self.infos

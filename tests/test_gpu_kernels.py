@@ -379,3 +379,53 @@ def test_flat_optimizer_with_gradient_sink_matches_torch_adam():
     finally:
         ops.SINK = None
         ops.set_precision("bf16")
+
+
+def test_graphed_train_step_matches_eager_steps():
+    """GraphedTrainStep (loss fwd + bwd + fused Adam/EMA replayed from one hipGraph) against the eager train_step on a
+    twin model with the same fixed draws: identical launches, so parameters and EMA must agree to rounding."""
+    import copy
+    import diffuser.models as DM
+    from madiff_amd import ops
+    from madiff_amd.host import batch_to_device
+    from madiff_amd.trainer import FlatAdamEMA, GraphedTrainStep, train_step
+    from oracle import madiff_oracle as O
+    dev = _dev()
+    ops.set_precision("fp32")
+    try:
+        torch.manual_seed(0)
+        A, T, Fd, B = 3, 24, 16, 4
+        net = DM.SharedConvAttentionDeconv(horizon=T, transition_dim=Fd, dim=32, dim_mults=(1, 4, 8), n_agents=A,
+                                           returns_condition=True, condition_dropout=0.25)
+        dif = DM.GaussianDiffusion(net, n_agents=A, horizon=T, history_horizon=0, observation_dim=Fd, action_dim=5,
+                                   n_timesteps=50, returns_condition=True, hidden_dim=64).to(dev)
+        for a in net.self_attn:
+            a.gamma.data.fill_(0.3)
+        batch = batch_to_device(O.synthetic_batch(B, T, A, Fd, 5, 0, seed=1), dev)
+        g = torch.Generator().manual_seed(5)
+        draws = dict(t=torch.randint(0, 50, (B,), generator=g).to(dev), noise=torch.randn(B, T, A, Fd, generator=g).to(dev),
+                     dropout_mask=(torch.rand(B, A, 1, generator=g) < 0.75).float().to(dev))
+        results = []
+        for mode in ("eager", "graph"):
+            m = copy.deepcopy(dif)
+            ema = copy.deepcopy(m)
+            opt = FlatAdamEMA(m, ema, lr=1e-3, ema_decay=0.9)
+            train_step(m, opt, [{**batch, **draws}], do_ema=2)          # materialises the flat buffers
+            if mode == "eager":
+                for i in range(4):
+                    loss, _ = train_step(m, opt, [{**batch, **draws}], do_ema=i % 2)
+            else:
+                gs = GraphedTrainStep(m, opt, batch, draws=draws)        # its constructor performs one eager step
+                for i in range(1, 4):
+                    loss, _ = gs.step(batch, do_ema=i % 2)
+            torch.cuda.synchronize()
+            assert opt.step_count == 5
+            results.append((float(loss), opt.flat_p.clone(), opt.flat_ema.clone()))
+            ops.SINK = None
+        (l0, p0, e0), (l1, p1, e1) = results
+        assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+        assert rel_err(p1.cpu(), p0.cpu()) < 1e-5
+        assert rel_err(e1.cpu(), e0.cpu()) < 1e-5
+    finally:
+        ops.SINK = None
+        ops.set_precision("bf16")
