@@ -64,9 +64,12 @@ int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, int taps, int
 
 /* Weight gradient of the above: dW[o, tap*Cin + c] (+)= sum_m dY[m, o] * X[src(m, tap), c]  (fp32 output).
  * Replaces the wgrad half of autograd for the same modules.  accumulate != 0 adds into dW (a live gradient buffer
- * kept in this GEMM layout by the flat optimizer), 0 overwrites.  tile: output tile (O x C) of the gfx950 LDS-DMA kernel,
- * 0..3 = {128x128, 128x64, 64x128, 64x64}, < 0 = library's choice; splits: number of slices the reduction over rows is
- * cut into (slices combine with fp32 atomics), <= 0 = library's choice. */
+ * kept in this GEMM layout by the flat optimizer), 0 overwrites.  tile: variant of the gfx950 LDS-DMA kernel, < 0 =
+ * library's choice; 0..3 = one workgroup per (O x C, tap) tile {128x128, 128x64, 64x128, 64x64}; 4..7 = ALL taps of a
+ * stride-1 "same" k5 convolution in one pass (operands staged once per K-step, tap shift applied by the transposing LDS
+ * reads) with tiles {64x64, 64x64, 128x64, 128x64} and {2, 3, 2, 3} LDS stages -- these return 1 (nothing launched) when
+ * the layer is not such a convolution or its sequence length divides neither 32 nor 96.  splits: number of slices the
+ * reduction over rows is cut into (slices combine with fp32 atomics), <= 0 = library's choice. */
 int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,
                       int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,
                       int ldw, int Nout, int accumulate, int tile, int splits, madiff_stream_t stream);

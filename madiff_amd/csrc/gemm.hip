@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __re
 // ------------------------------------------------------------------------------------------------
 extern "C" int madiff_launch_gemm_fwd_bf16(const void* params, int out_f32, int tile, hipStream_t stream);
 extern "C" int madiff_launch_gemm_wgrad_bf16(const void* params, int tile, int gx, int gy, int gz, hipStream_t stream);
+extern "C" int madiff_launch_gemm_wgrad_taps_bf16(const void* params, int variant, int nq, int gx, int gy, int gz, hipStream_t stream);
 
 // MADIFF_GEMM_IMPL=0 forces the generic register-staged kernel for bf16 too (A/B timing, debugging)
 static int use_dma_kernel() {
@@ -460,11 +461,11 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
                                  int ldx2, int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride,
                                  int pad, int tr, float* dW, int ldw, int Nout, int accumulate, int tile, int splits,
                                  hipStream_t stream) {
-  static const int kBO[4] = {128, 128, 64, 64}, kBC[4] = {128, 64, 128, 64};
+  static const int kBO[8] = {128, 128, 64, 64, 64, 64, 128, 128}, kBC[8] = {128, 64, 128, 64, 64, 64, 64, 64};
   const int es = dtype == MADIFF_BF16 ? 2 : 4;
   if (M <= 0 || Nout <= 0) return 0;
   if (check_rowmap(T_out, T_in, stride, pad, tr) || Cin <= 0 || Cin % 32 || taps <= 0 || ldw < taps * Cin ||
-      Ycols % 32 || ldy < Ycols || (ldy * es) % 16 || (ldx * es) % 16 || M % T_out || tile >= 4)
+      Ycols % 32 || ldy < Ycols || (ldy * es) % 16 || (ldx * es) % 16 || M % T_out || tile >= 8)
     return -1;
   if (X2 == nullptr) Csplit = Cin;
   if (Csplit > Cin || ldx < Csplit || (X2 && (Csplit % 128 || ldx2 < Cin - Csplit || (ldx2 * es) % 16))) return -1;
@@ -473,12 +474,17 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
   p.M = M; p.Cin = Cin; p.taps = taps; p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.dW = dW; p.ldw = ldw; p.Nout = Nout; p.accumulate = accumulate ? 1 : 0;
   const bool dma = dtype == MADIFF_BF16 && use_dma_kernel() && T_out < 256 && M < (1 << 24);
+  // all-taps kernel (variants 4..7): stride-1 "same" k5 convolutions whose sequence length divides 32 or 96 rows
+  const int nq = (32 % T_out == 0) ? 1 : ((96 % T_out == 0) ? 3 : 0);
+  const bool taps_ok = dma && taps == 5 && stride == 1 && tr == 0 && T_in == T_out && pad == 2 && nq > 0;
+  if (tile >= 4 && !taps_ok) return 1;                 // variant not applicable to this layer (caller picks another)
   if (!dma || tile < 0) tile = 0;
   const int BO = kBO[tile], BC = kBC[tile];
+  const bool all_taps = tile >= 4;
   p.ctiles = (Cin + BC - 1) / BC;
-  const int KR = dma ? 64 : (dtype == MADIFF_BF16 ? 32 : 16);
+  const int KR = all_taps ? 32 * nq : (dma ? 64 : (dtype == MADIFF_BF16 ? 32 : 16));
   int total_steps = (M + KR - 1) / KR;
-  int tiles = ((Nout + BO - 1) / BO) * p.ctiles * taps;
+  int tiles = ((Nout + BO - 1) / BO) * p.ctiles * (all_taps ? 1 : taps);
   if (splits <= 0) {
     // every extra split costs one more fp32 atomic pass over dW (atomics run at ~1.3 TB/s chip-wide), so only split
     // the reduction as far as needed to put ~2 workgroups on each of the 256 CUs
@@ -495,6 +501,8 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
     hipError_t e = hipMemsetAsync(dW, 0, (size_t)Nout * ldw * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
   }
+  if (all_taps)
+    return madiff_launch_gemm_wgrad_taps_bf16(&p, tile, nq, (Nout + BO - 1) / BO, p.ctiles, p.splits, stream);
   dim3 grid((Nout + BO - 1) / BO, p.ctiles * taps, p.splits), block(256);
   if (dma) return madiff_launch_gemm_wgrad_bf16(&p, tile, grid.x, grid.y, grid.z, stream);
   if (dtype == MADIFF_BF16) hipLaunchKernelGGL((gemm_wgrad_kernel<bf16_t>), grid, block, 0, stream, p);

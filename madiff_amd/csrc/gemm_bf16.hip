@@ -507,3 +507,193 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_wgrad_bf
   MADIFF_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient of a stride-1 "same" convolution, ALL TAPS IN ONE PASS (bf16):
+//   dW[o, k*Cin + c] (+)= sum_{n,t} dY[(n,t), o] * X[(n, t + k - pad), c]      k = 0..TAPS-1, rows outside the sequence = 0
+// The per-tap kernel above re-reads the same dY tile and (row-shifted) the same X tile once per tap.  Here a workgroup
+// owns a BO x BC tile of (o, c) for every tap: one K-step stages KR = 32*NQ rows = a whole number of sequences of dY
+// and X ONCE, and the tap shift happens in LDS: ds_read_b64_tr_b16 takes a row address per lane, so the X fragment of
+// tap k is read from rows (m + k - pad), and a lane whose (m, k) pair crosses a sequence boundary points at a
+// zero row kept in LDS instead.  No masking VALU, no row arithmetic in the loop (all LDS offsets are loop-invariant
+// registers), 1/TAPS of the DMA traffic and TAPS x the MFMAs per staged byte.
+// NQ: 32-row chunks per K-step; requires (32*NQ) % T == 0 (T in {2,4,8,16,32} -> NQ 1; T in {3,6,12,24,...} -> NQ 3).
+// ------------------------------------------------------------------------------------------------
+template <int BO, int BC, int TAPS, int NQ, int D>
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_taps_bf16_kernel(GemmWgradParams p) {
+  static_assert(BC == 64, "X tile: 128-byte rows");
+  constexpr int KR = 32 * NQ;
+  constexpr int MI = BO / 32, NJ = BC / 32;
+  constexpr int Y_BYTES = KR * BO * 2, X_BYTES = KR * BC * 2;
+  constexpr int ZERO_OFF = Y_BYTES + X_BYTES;            // 128 zero bytes behind the tiles of every stage
+  constexpr int BUF_BYTES = ZERO_OFF + 1024;             // (stages stay 1 KB aligned for the DMA pieces)
+  constexpr int YCH = BO / 8;                            // chunks per dY row (8 or 16)
+  constexpr int YRP = 64 / YCH;                          // rows per DMA piece
+  constexpr int YP = KR / YRP / 4, XP = KR / 8 / 4;      // pieces per wave per stage
+  static_assert((KR / YRP) % 4 == 0 && (KR / 8) % 4 == 0, "pieces must split evenly over 4 waves");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[D * BUF_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int n0 = blockIdx.x * BO, c0 = blockIdx.y * BC;
+  const int T = p.rm.T_out, pad = p.rm.pad;
+  const int total_steps = (p.M + KR - 1) / KR;
+  const int s_begin = blockIdx.z * p.steps_per_split;
+  int s_end = s_begin + p.steps_per_split;
+  if (s_end > total_steps) s_end = total_steps;
+  if (s_begin >= s_end) return;
+  const int nsteps = s_end - s_begin;
+  if (tid < 32 * D) ((float*)(smem + (tid >> 5) * BUF_BYTES + ZERO_OFF))[tid & 31] = 0.f;
+  __syncthreads();
+
+  const unsigned char* xsrc = (const unsigned char*)p.X;
+  int ldx = p.ldx, cx = c0, cmax = p.Csplit;
+  if (c0 >= p.Csplit) { xsrc = (const unsigned char*)p.X2; ldx = p.ldx2; cx = c0 - p.Csplit; cmax = p.Cin - p.Csplit; }
+
+  // DMA pieces: piece q of a tile covers rows [q*RP, (q+1)*RP); wave w issues pieces w*P .. w*P + P-1.  The source row of
+  // K-step row r is simply step*KR + r for both operands: the tap shift is applied when the fragments are read.
+  int yrow[YP], xrow[XP];
+  const unsigned char* ysrc0[YP];
+  const unsigned char* xsrc0[XP];
+#pragma unroll
+  for (int j = 0; j < YP; j++) {
+    yrow[j] = (YP * wave + j) * YRP + lane / YCH;
+    int ch = (lane % YCH) ^ tr_swz<BO>(yrow[j]);
+    ysrc0[j] = n0 + ch * 8 < p.Ycols ? (const unsigned char*)p.dY + ((size_t)yrow[j] * p.ldy + n0 + ch * 8) * 2 : nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < XP; j++) {
+    xrow[j] = (XP * wave + j) * 8 + (lane >> 3);
+    int ch = (lane & 7) ^ tr_swz<BC>(xrow[j]);
+    xsrc0[j] = cx + ch * 8 < cmax ? xsrc + ((size_t)xrow[j] * ldx + cx + ch * 8) * 2 : nullptr;
+  }
+  const unsigned char* zero = g_zero_page + (lane & 15) * 16;
+  auto issue = [&](int buf, int s) {
+    unsigned char* base = &smem[buf * BUF_BYTES];
+    const size_t m0 = (size_t)s * KR;
+#pragma unroll
+    for (int j = 0; j < YP; j++) {
+      const unsigned char* g = (ysrc0[j] && m0 + yrow[j] < (size_t)p.M) ? ysrc0[j] + m0 * p.ldy * 2 : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(base + (YP * wave + j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+      const unsigned char* g = (xsrc0[j] && m0 + xrow[j] < (size_t)p.M) ? xsrc0[j] + m0 * ldx * 2 : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(base + Y_BYTES + (XP * wave + j) * 1024), 16, 0, 0);
+    }
+  };
+
+  // loop-invariant, stage-relative LDS offsets of the fragment reads (the MFMA block index i / j is XORed in: it only
+  // touches chunk-index bit 1, which the swizzle XORs too, and XOR commutes)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tq = fr >> 2, tp = fr & 3;
+  const int o8 = 8 * (tp & 1);
+  int yoff[NQ][2], xoff[NQ][2][TAPS];
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int r = 32 * q + 8 * fq + tq + 4 * h;          // row of the K-step (the same for every step)
+      yoff[q][h] = r * (BO * 2) + ((((YCH / 2) * wn + (tp >> 1)) ^ tr_swz<BO>(r)) << 4) + o8;
+      const int t = r % T;
+#pragma unroll
+      for (int k = 0; k < TAPS; k++) {
+        const int ts = t + k - pad, rs = r + k - pad;       // KR % T == 0: a valid shifted row stays inside the K-step
+        xoff[q][h][k] = (ts >= 0 && ts < T) ? Y_BYTES + rs * (BC * 2) + (((4 * wc + (tp >> 1)) ^ tr_swz<BC>(rs)) << 4) + o8
+                                             : ZERO_OFF + ((tp >> 1) << 4) + o8;
+      }
+    }
+
+  f32x4 acc[TAPS][MI][NJ];
+#pragma unroll
+  for (int k = 0; k < TAPS; k++)
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[k][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  constexpr int PIECES = YP + XP;
+  int issued = 0, ibuf = 0;
+#pragma unroll
+  for (int d = 0; d < D - 1; d++)
+    if (d < nsteps) { issue(ibuf, s_begin + issued); ++issued; if (++ibuf == D) ibuf = 0; }
+  int buf = 0;
+  for (int s = 0; s < nsteps; s++) {
+    if (s + D - 1 <= nsteps) wait_vmcnt<(D - 2) * PIECES>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (issued < nsteps) { issue(ibuf, s_begin + issued); ++issued; if (++ibuf == D) ibuf = 0; }
+    const unsigned char* B0 = &smem[buf * BUF_BYTES];
+    if (++buf == D) buf = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      bf16x8 a[MI];
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (yoff[q][0] ^ (i << 5))));
+        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (yoff[q][1] ^ (i << 5))));
+        a[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int k = 0; k < TAPS; k++) {
+        bf16x8 b[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (xoff[q][0][k] ^ (j << 5))));
+          s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (xoff[q][1][k] ^ (j << 5))));
+          b[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+            acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[k][i][j], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < TAPS; k++)
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int n = n0 + wn * (BO / 2) + i * 16 + fq * 4 + r;
+        if (n >= p.Nout) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          int c = c0 + wc * (BC / 2) + j * 16 + fr;
+          if (c >= p.Cin) continue;
+          float* dst = p.dW + (size_t)n * p.ldw + (size_t)k * p.Cin + c;
+          if (p.splits > 1) atomicAdd(dst, acc[k][i][j][r]);
+          else if (p.accumulate) *dst += acc[k][i][j][r];
+          else *dst = acc[k][i][j][r];
+        }
+      }
+}
+
+// variant ids 4..7 of madiff_gemm_wgrad: all-taps kernel, {64x64, 128x64} (O x C) x {2, 3} LDS stages; nq = 32-row
+// chunks per K-step (1 or 3), chosen by the caller from the sequence length
+extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_wgrad_taps_bf16(const void* params, int variant, int nq,
+                                                                                        int gx, int gy, int gz,
+                                                                                        hipStream_t stream) {
+  const GemmWgradParams& p = *(const GemmWgradParams*)params;
+  if (p.taps != 5 || (nq != 1 && nq != 3)) return -1;
+  dim3 grid(gx, gy, gz);
+#define MADIFF_WT(V, BO_, D_)                                                                                           \
+  case V:                                                                                                               \
+    if (nq == 3) hipLaunchKernelGGL((gemm_wgrad_taps_bf16_kernel<BO_, 64, 5, 3, D_>), grid, dim3(256), 0, stream, p);   \
+    else hipLaunchKernelGGL((gemm_wgrad_taps_bf16_kernel<BO_, 64, 5, 1, D_ + 1>), grid, dim3(256), 0, stream, p);       \
+    break;
+  switch (variant) {
+    MADIFF_WT(4, 64, 2)
+    MADIFF_WT(5, 64, 3)
+    MADIFF_WT(6, 128, 2)
+    MADIFF_WT(7, 128, 3)
+    default: return -1;
+  }
+#undef MADIFF_WT
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}

@@ -340,28 +340,31 @@ def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncol
     return gx.to(act_dtype()) if ksplit > 1 else gx
 
 
-_WGRAD_TILES = ((128, 128), (128, 64), (64, 128), (64, 64))      # (O, C) output tiles of gemm_wgrad_bf16_kernel
+# variants of madiff_gemm_wgrad: (O tile, C tile, all taps in one pass?); 4..7 = {64x64, 128x64} x {2, 3} LDS stages
+_WGRAD_TILES = ((128, 128, 0), (128, 64, 0), (64, 128, 0), (64, 64, 0), (64, 64, 1), (64, 64, 1), (128, 64, 1), (128, 64, 1))
 
 
 def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, accumulate=0):
     def launch(dst, acc, tile, splits):
-        lib.call("madiff_gemm_wgrad", _dt(), dy.data_ptr(), dy.stride(0), dy.shape[1], x.data_ptr(), x.stride(0), _p(x2),
-                 0 if x2 is None else x2.stride(0), csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad,
-                 spec.tr, dst.data_ptr(), dst.stride(0), nout, acc, tile, splits, _stream())
+        return lib.call_rc("madiff_gemm_wgrad", _dt(), dy.data_ptr(), dy.stride(0), dy.shape[1], x.data_ptr(),
+                           x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0), csplit, M, cin, spec.taps, t_out, t_in,
+                           spec.stride, spec.pad, spec.tr, dst.data_ptr(), dst.stride(0), nout, acc, tile, splits,
+                           _stream())
 
     sig = ("wgrad", M, cin, spec.taps, nout, t_out, spec.stride, spec.tr, x2 is not None, accumulate)
     cfg = _TUNE.get(sig)
     if cfg is None and _AUTOTUNE and _PRECISION == "bf16" and not torch.cuda.is_current_stream_capturing():
-        # time every (tile, reduction split) candidate on the real operands into a scratch matrix
+        # time every (variant, reduction split) candidate on the real operands into a scratch matrix
         scratch = torch.empty(nout, dW.shape[1], dtype=torch.float32, device=dW.device)
-        steps = (M + 63) // 64
         best, best_ms = (-1, 0), float("inf")
-        for tile, (bo, bc) in enumerate(_WGRAD_TILES):
-            tiles = -(-nout // bo) * -(-cin // bc) * spec.taps
-            for splits in (1, 2, 3, 4, 6, 8):
-                if splits > 1 and (splits > steps // 4 or tiles * splits > 4096):
+        for tile, (bo, bc, all_taps) in enumerate(_WGRAD_TILES):
+            steps = (M + 63) // 64
+            tiles = -(-nout // bo) * -(-cin // bc) * (1 if all_taps else spec.taps)
+            for splits in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+                if splits > 1 and (splits > steps // 4 or tiles * splits > 2048):
                     continue
-                launch(scratch, 1, tile, splits)
+                if launch(scratch, 1, tile, splits) != 0:
+                    break                      # variant not applicable to this layer
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):

@@ -58,11 +58,14 @@ for name, T, ci, co, spec, cnt in shapes:
     dW = torch.zeros(co, spec.taps * ci, dtype=torch.float32, device=dev)
     wg = {}
     steps = (M + 63) // 64
-    for tile, (bo, bc) in enumerate(ops._WGRAD_TILES):
-        for splits in (1, 2, 3, 4, 6, 8):
-            if splits > 1 and (splits > steps // 4 or (co // bo) * (ci // bc) * spec.taps * splits > 4096):
+    for tile, (bo, bc, all_taps) in enumerate(ops._WGRAD_TILES):
+        for splits in (1, 2, 3, 4, 6, 8, 16):
+            if splits > 1 and (splits > steps // 4 or (co // bo) * (ci // bc) * (1 if all_taps else spec.taps) * splits > 2048):
                 continue
-            wg[(tile, splits)] = timeit(lambda: ops.lib.call(
+            if ops.lib.call_rc("madiff_gemm_wgrad", 1, gy.data_ptr(), co, co, x.data_ptr(), ci, None, 0, ci, M, ci, spec.taps,
+                               T, T, 1, spec.pad, 0, dW.data_ptr(), dW.stride(0), co, 1, tile, splits, st) != 0:
+                break
+            wg[(tile, splits)] = timeit(lambda: ops.lib.call_rc(
                 "madiff_gemm_wgrad", 1, gy.data_ptr(), co, co, x.data_ptr(), ci, None, 0, ci, M, ci, spec.taps, T, T, 1,
                 spec.pad, 0, dW.data_ptr(), dW.stride(0), co, 1, tile, splits, st), n=10)
     kbest = min(wg, key=wg.get)
