@@ -1,0 +1,327 @@
+// All-taps implicit-GEMM kernel for stride-1 "same" k = 5 convolutions (bf16 storage, fp32 accumulate), forward and
+// data gradient.  Reference op: nn.Conv1d(k=5, padding=2) inside Conv1dBlock (helpers.py:50-74), 24 of the 25 conv
+// blocks of one denoiser forward, and the same layers' input gradients.
+//
+// Why a second kernel: gemm_fwd_bf16_kernel treats every (tap, 64-channel chunk) as an independent K-step and stages
+// the activation tile again for each of the 5 taps, although the 5 tiles are the SAME rows shifted by tap - pad.  At
+// 18 operand bytes per algorithmic kFLOP that kernel is bound by the L2 -> LDS rate (and by the issue cost of its
+// LDS-DMA pieces), not by the MFMA pipe.  Here an output tile is a whole number of sequences, the activation chunk
+// [BM rows x 64 channels] is staged ONCE per channel chunk and used by all 5 taps: the tap shift is applied when the
+// MFMA A-fragments are read (ds_read_b128 takes a row address per lane; a lane whose shifted row leaves its sequence
+// reads a zero row kept in LDS).  Per channel chunk the workgroup stages 1 activation tile + 5 weight tiles instead of
+// 5 + 5: 6.6 B/kFLOP with the 192-row tile, 11.7 with the 96-row one.
+//
+//   tile        BM x 128 outputs, BM = 48 * WM rows (WM = 4: 192 rows, 8 waves, one workgroup per CU;
+//               WM = 2: 96 rows, 4 waves, two per CU); wave tile 48 x 64 = 3 x 4 MFMA 16x16x32 blocks
+//   rows        a tile holds SPT = BM / T whole sequences (rows_used = SPT * T <= BM; unused rows are zero-filled
+//               and never stored), so any sequence length T <= BM works (6/12/24 use every row)
+//   A buffers   2 x [BM rows][64 ch] (128-byte rows, 16-byte chunk index XORed with row & 7 on the DMA source side
+//               and on the read side) + 1 KB of zeros behind each (the zero row)
+//   W ring      D x 16 KB (D = 4 / 3): WT = false [128 n][64 k] as A;  WT = true [64 k][128 n] read with ds_read_b64_tr_b16
+//               (the data gradient reads the FORWARD weight matrix, no transposed copy)
+//   pipeline    step s = (chunk c, tap): counted s_waitcnt vmcnt -> one raw s_barrier -> issue W(s+2) (and A(c+1) at
+//               tap 0) -> 24 MFMAs per wave.  Two W stages and one A stage stay in flight across the barrier.
+//   epilogue    bias / row-bias / activation on 8-column vectors through a wave-private LDS tile, 16-byte stores.
+#include "gemm_params.h"
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ int ct_wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+template <int N> __device__ __forceinline__ void ct_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One LDS-DMA piece: 64 lanes x 16 bytes, global (uniform base + 32-bit lane offset) -> LDS [lds_addr + 16 * lane].
+// Issued through inline asm on purpose: hipcc models the builtin form as a FLAT access that may touch LDS, and while any
+// such access is outstanding (here: always) its waitcnt pass turns EVERY lgkmcnt wait into lgkmcnt(0), i.e. each
+// fragment read would drain the whole LDS queue.  Hidden in asm, the DMA is ordered by the explicit vmcnt waits and
+// barriers below (all carry memory clobbers) and the ds_reads get exact counted waits.
+__device__ __forceinline__ void ct_dma16(const void* gbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(gbase)
+               : "memory");
+}
+
+// shift(tap) = shift0 + tap * shift_step: forward (tr = 0) -pad + tap, data gradient (tr = 1) pad - tap
+template <int WM, bool WT, int D>
+__global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams p, int rows_used, int shift0, int shift_step) {
+  constexpr int TAPS = 5;
+  static_assert(D == 3 || D == 4, "W ring depth");
+  constexpr int BM = 48 * WM, NW = 2 * WM, NT = NW * 64;
+  constexpr int MI = 3, NJ = 4;
+  constexpr int A_TILE = BM * 128, A_BYTES = A_TILE + 1024, W_BYTES = 128 * 128;
+  constexpr int AP = (BM / 8) / NW;        // A DMA pieces (1 KB = 8 rows x 128 B) per wave = 3
+  constexpr int WP = 16 / NW;              // W DMA pieces per wave
+  static_assert(AP * NW * 8 == BM && WP * NW == 16, "pieces must split evenly over the waves");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES + D * W_BYTES];
+  unsigned char* const Wbase = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int T = p.rm.T_out;
+  const int m0 = blockIdx.x * rows_used, n0 = blockIdx.y * 128;
+
+  for (int i = tid; i < 512; i += NT) ((float*)(smem + (i >> 8) * A_BYTES + A_TILE))[i & 255] = 0.f;   // zero rows
+
+  // ---- DMA sources.  Rows / columns outside the problem are CLAMPED to a valid one instead of being zero-filled:
+  // what they produce lands only in output rows that are never stored or in pad columns the epilogue writes as 0,
+  // so every lane's source is (uniform base) + (32-bit lane offset) with no per-piece select.
+  unsigned a_off[2][AP];                   // lane offset into X (and into X2, the second source of a skip concat)
+#pragma unroll
+  for (int j = 0; j < AP; j++) {
+    const int row = (AP * wave + j) * 8 + (lane >> 3);
+    const unsigned c16 = ((lane & 7) ^ (row & 7)) << 4;
+    const unsigned grow = row < rows_used ? min(m0 + row, p.M - 1) : m0;
+    a_off[0][j] = grow * (unsigned)(p.ldx * 2) + c16;
+    a_off[1][j] = grow * (unsigned)(p.ldx2 * 2) + c16;
+  }
+  unsigned w_off[WP];
+#pragma unroll
+  for (int j = 0; j < WP; j++) {
+    if constexpr (!WT) {
+      const int row = (WP * wave + j) * 8 + (lane >> 3);
+      const int wr = min(n0 + row, p.Nout - 1);
+      w_off[j] = (unsigned)wr * (unsigned)(p.ldw * 2) + (((lane & 7) ^ (row & 7)) << 4);
+    } else {
+      const int krow = (WP * wave + j) * 4 + (lane >> 4);
+      const int ch = (lane & 15) ^ ct_wg_swz(krow);
+      const int col = min(n0 + ch * 8, p.wcols - 8);
+      w_off[j] = ((unsigned)krow * (unsigned)p.ldw + (unsigned)col) * 2;
+    }
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  auto issueA = [&](int c) {
+    int c0 = c << 6;
+    const unsigned char* xb = (const unsigned char*)p.X;
+    const bool second = c0 >= p.Csplit;
+    if (second) { xb = (const unsigned char*)p.X2; c0 -= p.Csplit; }
+    xb += c0 * 2;
+    const unsigned base = lds0 + (c & 1) * A_BYTES + AP * wave * 1024;
+#pragma unroll
+    for (int j = 0; j < AP; j++) ct_dma16(xb, second ? a_off[1][j] : a_off[0][j], base + j * 1024);
+  };
+  auto issueW = [&](int tap, int c, int slot) {
+    const unsigned char* wb = (const unsigned char*)p.W +
+                              (WT ? ((size_t)(c << 6) * p.ldw + (size_t)tap * p.wtap) * 2 : ((size_t)tap * p.Cin + (c << 6)) * 2);
+    const unsigned base = lds0 + 2 * A_BYTES + slot * W_BYTES + WP * wave * 1024;
+#pragma unroll
+    for (int j = 0; j < WP; j++) ct_dma16(wb, w_off[j], base + j * 1024);
+  };
+
+  // ---- loop-invariant LDS offsets of the fragments.  A: row shifted by the tap and its swizzled chunk; a lane whose
+  // shifted row leaves the sequence reads the zero block at the SAME bank position it would have had (so the access
+  // stays conflict-free).  kh = 1 toggles chunk bit 2 = byte offset ^ 64 everywhere.
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tq = fr >> 2, tp = fr & 3;
+  int offA[TAPS][MI];
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+    const int ra = wm * 48 + i * 16 + fr;
+    const int t = ra % T;
+#pragma unroll
+    for (int k = 0; k < TAPS; k++) {
+      const int sh = shift0 + k * shift_step;
+      const int ts = t + sh, rs = ra + sh;
+      const int nat = rs * 128 + ((fq ^ (rs & 7)) << 4);
+      offA[k][i] = (ra < rows_used && ts >= 0 && ts < T) ? nat : A_TILE + (nat & 255);
+    }
+  }
+  int offB[2];
+  if constexpr (!WT) {
+    const int rb = wn * 64 + fr;                          // + 16 j rows = + 2048 j bytes
+    offB[0] = rb * 128 + ((fq ^ (rb & 7)) << 4);
+    offB[1] = 0;
+  } else {
+    const int r0 = 8 * fq + tq, r1 = r0 + 4;              // + 32 kh rows = + 8192 kh bytes (the swizzle ignores bit 5 of the row)
+    const int cb = 8 * wn + (tp >> 1), o = 8 * (tp & 1);  // + 2 j chunks = ^ (j << 5) bytes
+    offB[0] = r0 * 256 + ((cb ^ ct_wg_swz(r0)) << 4) + o;
+    offB[1] = r1 * 256 + ((cb ^ ct_wg_swz(r1)) << 4) + o;
+  }
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto load_frags = [&](bf16x8 (&a)[MI], bf16x8 (&b)[NJ], const unsigned char* As, const unsigned char* Ws, const int (&oa)[MI],
+                        const int kh) {
+#pragma unroll
+    for (int i = 0; i < MI; i++) a[i] = *(const bf16x8*)(As + (oa[i] ^ (kh << 6)));
+    if constexpr (!WT) {
+      const unsigned char* wp = Ws + (offB[0] ^ (kh << 6));
+#pragma unroll
+      for (int j = 0; j < NJ; j++) b[j] = *(const bf16x8*)(wp + j * 2048);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Ws + kh * 8192 + (offB[0] ^ (j << 5))));
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Ws + kh * 8192 + (offB[1] ^ (j << 5))));
+        b[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    }
+  };
+  auto mma = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- software pipeline.  Invariant at the top of step s = (c, tap): the kh = 0 fragments of step s are (being) loaded
+  // into a0/b0, W(s) and A(c) are visible to every wave, W(s+1) .. W(s+D-2) are in flight.
+  const int nc = p.Cin >> 6;
+  bf16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
+  __syncthreads();                         // zero rows written before any fragment read
+  issueA(0);
+#pragma unroll
+  for (int d = 0; d < D - 1; d++) issueW(d, 0, d);
+  ct_wait_vmcnt<(D - 2) * WP>();
+  __builtin_amdgcn_s_barrier();
+  load_frags(a0, b0, smem, Wbase, offA[0], 0);
+  int slot = 0;                            // ring slot holding W(s)
+  for (int c = 0; c < nc; c++) {
+    const unsigned char* As = smem + (c & 1) * A_BYTES;
+    const unsigned char* An = smem + ((c + 1) & 1) * A_BYTES;
+    const bool lastc = c + 1 == nc;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; tap++) {
+      const bool last = lastc && tap == TAPS - 1;
+      int nslot = slot + 1;                // slot of W(s+1)
+      if (nslot == D) nslot = 0;
+      if (!last) {
+        // own pieces of W(s+1) landed.  Outstanding, oldest first: W(s+1), [A(c+1) when it was issued in step s-1],
+        // W(s+2) .. W(s+D-2) (those that exist)
+        if (tap == 1 && !lastc) ct_wait_vmcnt<(D - 3) * WP + AP>();
+        else if (tap == TAPS - 2 && lastc) ct_wait_vmcnt<0>();
+        else ct_wait_vmcnt<(D - 3) * WP>();
+        // every wave's W(s+1) (and, in order, anything older) is in LDS, and every wave has finished step s-1
+        __builtin_amdgcn_s_barrier();
+        // A(c+1) goes into the buffer A(c-1) occupied.  Order matters for the counted waits above: with D = 4, W(s+1) was
+        // issued two steps ago, so A may precede this step's W; with D = 3, W(s+1) is THIS step's W of the previous
+        // step and must be older than the A pieces that are allowed to stay outstanding at tap 1.
+        if (D == 4 && tap == 0 && !lastc) issueA(c + 1);
+        int tn = tap + D - 1, cn = c;
+        if (tn >= TAPS) { tn -= TAPS; cn = c + 1; }
+        int islot = slot + D - 1;                          // = the slot W(s-1) occupied
+        if (islot >= D) islot -= D;
+        if (cn < nc) issueW(tn, cn, islot);
+        if (D == 3 && tap == 0 && !lastc) issueA(c + 1);
+      }
+      const unsigned char* Ws = Wbase + slot * W_BYTES;
+      // sched_barrier(0): hipcc otherwise sinks each fragment read down to just before its MFMA, which undoes the
+      // prefetch distance; with the fences the reads of one phase fly under the MFMAs of the other
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(a1, b1, As, Ws, offA[tap], 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) {                                        // kh = 0 fragments of step s+1: legal before the next barrier
+        const unsigned char* Wn = Wbase + nslot * W_BYTES;
+        if (tap == TAPS - 1) load_frags(a0, b0, An, Wn, offA[0], 0);
+        else load_frags(a0, b0, As, Wn, offA[tap + 1 < TAPS ? tap + 1 : 0], 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      slot = nslot;
+    }
+  }
+
+  // ---- epilogue (vector path only; the launcher checks the alignment preconditions)
+  bf16_t* C = (bf16_t*)p.C;
+  constexpr int WN = 64, LDT = WN + 4, VPR = WN / 8, RPP = 64 / VPR;
+  __syncthreads();                         // every wave is done with the operand tiles; no DMA is outstanding
+  float* stage = (float*)smem + wave * (16 * LDT);
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) stage[(fq * 4 + r) * LDT + j * 16 + fr] = acc[i][j][r];
+#pragma unroll
+    for (int pass = 0; pass < 16 / RPP; pass++) {
+      const int row = pass * RPP + lane / VPR, cv = lane % VPR;
+      const f32x4 v0 = *(const f32x4*)&stage[row * LDT + cv * 8];
+      const f32x4 v1 = *(const f32x4*)&stage[row * LDT + cv * 8 + 4];
+      const int lr = wm * 48 + i * 16 + row;
+      const int m = m0 + lr;
+      const int n = n0 + wn * WN + cv * 8;
+      if (lr >= rows_used || m >= p.M || n >= p.Npad) continue;
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const int seq = m / T;
+      if (n + 8 <= p.Nout) {
+        if (p.bias) {
+          const f32x4 b0 = *(const f32x4*)&p.bias[n], b1 = *(const f32x4*)&p.bias[n + 4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        }
+        if (p.rowbias) {
+          const float* rb = p.rowbias + (size_t)seq * p.ldrb + n;
+          const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        }
+      } else {                              // the vector straddles / lies beyond the real columns: pad columns are 0
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          if (n + e < p.Nout) {
+            if (p.bias) v[e] += p.bias[n + e];
+            if (p.rowbias) v[e] += p.rowbias[(size_t)seq * p.ldrb + n + e];
+          } else {
+            v[e] = 0.f;
+          }
+        }
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = n + e < p.Nout ? mish_f(v[e]) : 0.f;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = (bf16_t)v[e];
+      *(bf16x8*)(C + (size_t)m * p.ldc + n) = o;
+    }
+  }
+}
+
+// variant: 0 = 192-row tile (8 waves), 1 = 96-row tile (4 waves).  Returns 1 when the layer is not covered.
+extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_bf16(const void* params, int out_f32, int variant,
+                                                                                  hipStream_t stream) {
+  GemmFwdParams p = *(const GemmFwdParams*)params;
+  const int BM = variant == 0 ? 192 : 96;
+  const int T = p.rm.T_out;
+  if (out_f32 || p.taps != 5 || p.rm.stride != 1 || p.rm.T_in != T || T > BM || p.permA > 0 || p.ksplit > 1 ||
+      p.Cin % 64 || p.Csplit % 64 || p.M % T)
+    return 1;
+  if (p.rm.pad < 0 || p.rm.pad > 4) return 1;
+  // lane offsets are 32-bit: operand extents must stay below 2 GiB
+  {
+    const size_t ldmax = (size_t)(p.ldx > p.ldx2 ? p.ldx : p.ldx2);
+    const size_t wext = p.wt ? (size_t)p.Cin * p.ldw * 2 : (size_t)p.Nout * p.ldw * 2;
+    if ((size_t)p.M * ldmax * 2 >= (1ull << 31) || wext >= (1ull << 31)) return 1;
+    if (p.wt && p.wcols < 8) return 1;
+  }
+  const bool vec_ok = p.Npad % 8 == 0 && ((size_t)p.C % 16) == 0 && ((size_t)p.ldc * 2) % 16 == 0 &&
+                      (!p.bias || (size_t)p.bias % 16 == 0) && (!p.rowbias || ((size_t)p.rowbias % 16 == 0 && p.ldrb % 4 == 0));
+  if (!vec_ok) return 1;
+  const int spt = BM / T, rows_used = spt * T;
+  const int n_seq = p.M / T;
+  const int shift0 = p.rm.tr ? p.rm.pad : -p.rm.pad, shift_step = p.rm.tr ? -1 : 1;
+  dim3 grid((n_seq + spt - 1) / spt, (p.Npad + 127) / 128);
+#define CT_LAUNCH(WM_, WT_, D_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, WT_, D_>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, shift0, shift_step)
+  if (variant == 0) {          // 192 rows: one 8-wave workgroup per CU, 4-deep W ring
+    if (p.wt) CT_LAUNCH(4, true, 4); else CT_LAUNCH(4, false, 4);
+  } else {                     // 96 rows: two 4-wave workgroups per CU (75 KB of LDS each), 3-deep W ring
+    if (p.wt) CT_LAUNCH(2, true, 3); else CT_LAUNCH(2, false, 3);
+  }
+#undef CT_LAUNCH
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}

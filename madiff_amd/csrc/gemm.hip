@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __re
 extern "C" int madiff_launch_gemm_fwd_bf16(const void* params, int out_f32, int tile, hipStream_t stream);
 extern "C" int madiff_launch_gemm_wgrad_bf16(const void* params, int tile, int gx, int gy, int gz, hipStream_t stream);
 extern "C" int madiff_launch_gemm_wgrad_taps_bf16(const void* params, int variant, int nq, int gx, int gy, int gz, hipStream_t stream);
+extern "C" int madiff_launch_conv_taps_bf16(const void* params, int out_f32, int variant, hipStream_t stream);
 
 // MADIFF_GEMM_IMPL=0 forces the generic register-staged kernel for bf16 too (A/B timing, debugging)
 static int use_dma_kernel() {
@@ -358,10 +359,13 @@ static int check_rowmap(int T_out, int T_in, int stride, int pad, int tr) {
 // shape and passes an explicit tile; this model is the fallback, e.g. under graph capture of an unseen shape).
 // Busiest CU holds nb = ceil(tiles / 256) workgroups; a lone workgroup runs at ~60 % of a CU's paired rate; smaller
 // tiles re-read more operand bytes per FLOP (eff).
-static const int kNumTiles = 14;
-static const int kTileBM[kNumTiles] = {128, 96, 64, 128, 96, 64, 128, 96, 64, 128, 96, 64, 64, 64};
-static const int kTileBN[kNumTiles] = {128, 128, 128, 64, 64, 64, 128, 128, 128, 64, 64, 64, 128, 64};
-static const int kTileD[kNumTiles] = {2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4};
+// ids 14, 15: the all-taps k5 kernel (conv_taps_bf16.hip), 192- and 96-row tiles; they cover stride-1 "same" k5 layers
+// only and the entry points return 1 ("not covered") for any other layer
+static const int kNumTiles = 16;
+static const int kFirstTapsTile = 14;
+static const int kTileBM[kNumTiles] = {128, 96, 64, 128, 96, 64, 128, 96, 64, 128, 96, 64, 64, 64, 192, 96};
+static const int kTileBN[kNumTiles] = {128, 128, 128, 64, 64, 64, 128, 128, 128, 64, 64, 64, 128, 64, 128, 128};
+static const int kTileD[kNumTiles] = {2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 3, 3};
 static int pick_tile(int M, int Npad, int wt) {
   static const double eff[6] = {1.0, 0.93, 0.85, 0.85, 0.78, 0.70};
   int best = 0;
@@ -411,6 +415,10 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   p.C = C; p.ldc = ldc; p.act = act; p.permT = permT; p.permA = permA;
   p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0;
   dim3 grid((M + 127) / 128, (Npad + 127) / 128), block(256);
+  if (tile >= kFirstTapsTile) {
+    if (dtype != MADIFF_BF16 || !use_dma_kernel()) return 1;
+    return madiff_launch_conv_taps_bf16(&p, out_f32, tile - kFirstTapsTile, stream);
+  }
   if (dtype == MADIFF_BF16 && Cin % 64 == 0 && Csplit % 64 == 0 && use_dma_kernel())
     return madiff_launch_gemm_fwd_bf16(&p, out_f32, tile >= 0 ? tile : pick_tile(M, Npad, 0), stream);
   if (dtype == MADIFF_BF16) {
@@ -454,6 +462,7 @@ extern "C" int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, in
     if (e != hipSuccess) return (int)e;
     return madiff_launch_gemm_fwd_bf16(&p, 1, 8, stream);       // 64x128, 3 stages, fp32 atomics
   }
+  if (tile >= kFirstTapsTile) return madiff_launch_conv_taps_bf16(&p, 0, tile - kFirstTapsTile, stream);
   return madiff_launch_gemm_fwd_bf16(&p, 0, tile >= 0 ? tile : pick_tile(M, Npad, 1), stream);
 }
 

@@ -279,10 +279,11 @@ def _tuned_tile(sig, candidates, launch) -> int:
         return -1
     best, best_ms = -1, float("inf")
     for tile in candidates:
-        launch(tile)
+        if launch(tile):                 # non-zero: the variant does not cover this layer (e.g. the all-taps k5 kernel)
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(3):
+        for _ in range(5):
             launch(tile)
         e1.record()
         e1.synchronize()
@@ -299,14 +300,17 @@ def _gemm(x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, tr, W, nout, npad,
     dma = _PRECISION == "bf16" and cin % 64 == 0 and csplit % 64 == 0
 
     def launch(tile):
-        lib.call("madiff_gemm_fwd", _dt(), out_f32, x.data_ptr(), x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0),
-                 csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad, tr, W.data_ptr(), W.stride(0), nout, npad,
-                 _p(bias), _p(rowbias), 0 if rowbias is None else rowbias.stride(0), out.data_ptr(), out.stride(0), act,
-                 perm[0] if perm else 0, perm[1] if perm else 0, tile, _stream())
+        return lib.call_rc("madiff_gemm_fwd", _dt(), out_f32, x.data_ptr(), x.stride(0), _p(x2),
+                           0 if x2 is None else x2.stride(0), csplit, M, cin, spec.taps, t_out, t_in, spec.stride, spec.pad,
+                           tr, W.data_ptr(), W.stride(0), nout, npad, _p(bias), _p(rowbias),
+                           0 if rowbias is None else rowbias.stride(0), out.data_ptr(), out.stride(0), act,
+                           perm[0] if perm else 0, perm[1] if perm else 0, tile, _stream())
 
-    tile = _tuned_tile(("fwd", M, cin, spec.taps, npad, t_out, spec.stride, tr, out_f32, x2 is not None),
+    tile = _tuned_tile(("fwd", M, cin, spec.taps, npad, t_out, spec.stride, tr, out_f32, x2 is not None,
+                        rowbias is not None, x.stride(0), out.stride(0)),
                        lib.tiles(), launch) if dma else -1
-    launch(tile)
+    if launch(tile) and launch(-1):      # (a tuned variant may not cover a same-shaped layer with other alignments)
+        raise RuntimeError(f"madiff_gemm_fwd: no kernel variant covers this layer")
 
 
 def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncols, ncols_pad):
@@ -335,8 +339,8 @@ def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncol
             return None
         if ksplit <= 1:
             _tuned_tile(sig, lib.tiles(wt=True), launch)   # remember the fastest variant (no-op under capture / if disabled)
-    else:
-        launch(tile)
+    elif launch(tile) and launch(-1):
+        raise RuntimeError("madiff_gemm_dgrad_wt: no kernel variant covers this layer")
     return gx.to(act_dtype()) if ksplit > 1 else gx
 
 

@@ -47,14 +47,16 @@ for name, T, ci, co, spec, cnt in shapes:
     st = ops._stream()
     fw = []
     for tile in range(len(TILES)):
-        fw.append(timeit(lambda: ops.lib.call("madiff_gemm_fwd", 1, 0, x.data_ptr(), ci, None, 0, ci, M, ci, spec.taps, T, T,
-                                              1, spec.pad, 0, Wf.data_ptr(), Wf.stride(0), co, co, None, None, 0,
-                                              y.data_ptr(), co, 0, 0, 0, tile, st)))
+        f = lambda: ops.lib.call_rc("madiff_gemm_fwd", 1, 0, x.data_ptr(), ci, None, 0, ci, M, ci, spec.taps, T, T,
+                                    1, spec.pad, 0, Wf.data_ptr(), Wf.stride(0), co, co, None, None, 0,
+                                    y.data_ptr(), co, 0, 0, 0, tile, st)
+        fw.append(timeit(f) if f() == 0 else float("inf"))      # rc 1: variant does not cover this layer
     dg = []
     for tile in WT_TILES:
-        dg.append(timeit(lambda: ops.lib.call_rc("madiff_gemm_dgrad_wt", gy.data_ptr(), co, M, co, spec.taps, T, T, 1,
-                                                 spec.pad, 1, Wf.data_ptr(), Wf.stride(0), ci, 0, ci, ci, dx.data_ptr(),
-                                                 ci, tile, 0, st)))
+        f = lambda: ops.lib.call_rc("madiff_gemm_dgrad_wt", gy.data_ptr(), co, M, co, spec.taps, T, T, 1,
+                                    spec.pad, 1, Wf.data_ptr(), Wf.stride(0), ci, 0, ci, ci, dx.data_ptr(),
+                                    ci, tile, 0, st)
+        dg.append(timeit(f) if f() == 0 else float("inf"))
     dW = torch.zeros(co, spec.taps * ci, dtype=torch.float32, device=dev)
     wg = {}
     steps = (M + 63) // 64

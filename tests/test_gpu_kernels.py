@@ -108,26 +108,37 @@ def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
     xcl = M.to_cl(x.detach())
     Wf = ops._packed([w.detach()], spec, False)
     st = torch.cuda.current_stream().cuda_stream
-    outs = []
+    # variants 0..13 (one K-step per tap and channel chunk) share one reduction order: bit-identical.  Variants 14, 15
+    # (all-taps k5 kernel, conv_taps_bf16.hip: channel-chunk-major order) cover stride-1 k5 layers only, agree with each
+    # other bit for bit and with the others to bf16 rounding.
+    FIRST_TAPS = 14
+    taps_case = case in ("conv5", "conv5_t24", "conv5_t8")
+    outs = {}
     for tile in range(lib.tile_count()):
         y = torch.full((N * T2, Co), float("nan"), dtype=torch.bfloat16, device=dev)
-        lib.call("madiff_gemm_fwd", lib.BF16, 0, xcl.data_ptr(), xcl.stride(0), None, 0, Cin, N * T2, Cin, k, T2, T,
-                 spec.stride, spec.pad, spec.tr, Wf.data_ptr(), Wf.stride(0), Co, Co, None, None, 0, y.data_ptr(), Co, 0,
-                 0, 0, tile, st)
-        outs.append(y)
+        rc = lib.call_rc("madiff_gemm_fwd", lib.BF16, 0, xcl.data_ptr(), xcl.stride(0), None, 0, Cin, N * T2, Cin, k, T2,
+                         T, spec.stride, spec.pad, spec.tr, Wf.data_ptr(), Wf.stride(0), Co, Co, None, None, 0,
+                         y.data_ptr(), Co, 0, 0, 0, tile, st)
+        assert rc == (0 if (tile < FIRST_TAPS or taps_case) else 1), (tile, rc)
+        if rc:
+            continue
+        outs[tile] = y
         assert rel_err(M.from_cl(y, N, T2, Co).cpu(), ref.detach().cpu()) < TOL["bf16"], tile
-        assert torch.equal(y, outs[0]), f"tile {tile} differs from tile 0"
+        base = outs[0] if tile < FIRST_TAPS else outs[FIRST_TAPS]
+        assert torch.equal(y, base), f"tile {tile} differs from tile {0 if tile < FIRST_TAPS else FIRST_TAPS}"
     gycl = M.to_cl(gy)
-    gxs = []
+    gxs = {}
     for tile in lib.tiles(wt=True):
         gx = torch.full((N * T, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
         rc = lib.call_rc("madiff_gemm_dgrad_wt", gycl.data_ptr(), gycl.stride(0), N * T, Co, k, T, T2, spec.stride,
                          spec.pad, 1 - spec.tr, Wf.data_ptr(), Wf.stride(0), Cin, 0, Cin, Cin, gx.data_ptr(), Cin, tile, 0,
                          st)
-        assert rc == 0
-        gxs.append(gx)
+        assert rc == (0 if (tile < FIRST_TAPS or taps_case) else 1), (tile, rc)
+        if rc:
+            continue
+        gxs[tile] = gx
         assert rel_err(M.from_cl(gx, N, T, Cin).cpu(), gx_ref.cpu()) < 3 * TOL["bf16"], tile
-        assert torch.equal(gx, gxs[0])
+        assert torch.equal(gx, gxs[0] if tile < FIRST_TAPS else gxs[FIRST_TAPS]), tile
     # sliced reduction (fp32 atomics, fp32 output)
     gx32 = torch.full((N * T, Cin), float("nan"), dtype=torch.float32, device=dev)
     rc = lib.call_rc("madiff_gemm_dgrad_wt", gycl.data_ptr(), gycl.stride(0), N * T, Co, k, T, T2, spec.stride, spec.pad,
