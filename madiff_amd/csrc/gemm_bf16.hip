@@ -34,6 +34,19 @@ __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row
 // Split-K: gridDim.z slices of the K-steps; slices combine with fp32 atomics (OutT = float, C pre-zeroed by the host).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// One LDS-DMA piece (64 lanes x 16 bytes: per-lane global address -> LDS [lds_addr + 16 * lane]).  Issued through inline
+// asm on purpose: hipcc models __builtin_amdgcn_global_load_lds as a FLAT access that may touch LDS, and while one is
+// outstanding (in these pipelines: always) its waitcnt pass turns every lgkmcnt wait into lgkmcnt(0), so each fragment
+// read drained the whole LDS queue.  Hidden in asm, the DMA is ordered by the explicit vmcnt waits and barriers (all
+// carry memory clobbers) and the ds_reads get exact counted waits.  lds_addr must be wave-uniform.
+__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :
+               : "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(gptr)
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_u32(const void* p) { return (unsigned)(uintptr_t)(lptr_t)p; }
+
 template <typename OutT, int BM, int BN, bool WT, int D>
 __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) {
   static_assert(!WT || BN == 128, "the transposed-read image is laid out for 256-byte rows");
@@ -41,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
   constexpr int A_BYTES = BM * 128, BUF_BYTES = (BM + BN) * 128;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[D * BUF_BYTES];   // [stage][A tile | W tile]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
@@ -100,13 +113,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
     for (int j = 0; j < MI; j++) {
       const unsigned char* ga = a_row[j] >= 0 ? xb + ((size_t)a_row[j] * ld + c) * 2 + a_chunk[j] * 16
                                               : g_zero_page + (lane & 7) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (MI * wave + j) * 1024), 16, 0, 0);
+      dma16(ga, lds_u32(base + (MI * wave + j) * 1024));
     }
     const size_t wk = WT ? ((size_t)c0 * p.ldw + (size_t)tap * p.wtap) * 2 : ((size_t)tap * p.Cin + c0) * 2;
 #pragma unroll
     for (int j = 0; j < WP; j++) {
       const unsigned char* gw = w_src[j] ? w_src[j] + wk : g_zero_page + (lane & 15) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)gw, (lptr_t)(base + A_BYTES + (WP * wave + j) * 1024), 16, 0, 0);
+      dma16(gw, lds_u32(base + A_BYTES + (WP * wave + j) * 1024));
     }
   };
 
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
   constexpr int YP = YCH / 4, XP = XCH / 4;              // DMA pieces (1 KB) per wave: wave w fills rows [16w, 16w+16)
   constexpr int YRP = 64 / YCH, XRP = 64 / XCH;          // rows per piece
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF_BYTES];   // [buf][dY tile | X tile]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wc = wave & 1;
   const int n0 = blockIdx.x * BO;
   const int tap = blockIdx.y / p.ctiles;
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
       int m = s * KR + yrow[j];
       const unsigned char* gy = zero;
       if (m < p.M && yok[j]) gy = (const unsigned char*)p.dY + ((size_t)m * p.ldy + n0 + ych[j] * 8) * 2;
-      __builtin_amdgcn_global_load_lds((gptr_t)gy, (lptr_t)(base + (YP * wave + j) * 1024), 16, 0, 0);
+      dma16(gy, lds_u32(base + (YP * wave + j) * 1024));
     }
 #pragma unroll
     for (int j = 0; j < XP; j++) {
@@ -422,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
         int r = map_row(n, m - n * p.rm.T_out, tap, p.rm);
         if (r >= 0) gx = xsrc + ((size_t)r * ldx + cx + xch[j] * 8) * 2;
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)gx, (lptr_t)(base + Y_BYTES + (XP * wave + j) * 1024), 16, 0, 0);
+      dma16(gx, lds_u32(base + Y_BYTES + (XP * wave + j) * 1024));
     }
   };
 
@@ -437,6 +450,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
   typedef s16x4 __attribute__((address_space(3))) * lds_p;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   issue(0, s_begin);
+  wait_vmcnt<0>();                 // the DMA is issued through asm: the compiler adds no vmcnt wait of its own
   __syncthreads();
   for (int s = s_begin; s < s_end; s++) {
     const int buf = (s - s_begin) & 1;
@@ -468,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
         for (int j = 0; j < NJ; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    wait_vmcnt<0>();               // stage s+1 landed (own pieces), then everyone's
     __syncthreads();
   }
 
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_taps_bf16_kernel(GemmWgradP
   constexpr int YP = KR / YRP / 4, XP = KR / 8 / 4;      // pieces per wave per stage
   static_assert((KR / YRP) % 4 == 0 && (KR / 8) % 4 == 0, "pieces must split evenly over 4 waves");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[D * BUF_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wc = wave & 1;
   const int n0 = blockIdx.x * BO, c0 = blockIdx.y * BC;
   const int T = p.rm.T_out, pad = p.rm.pad;
@@ -573,12 +588,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_taps_bf16_kernel(GemmWgradP
 #pragma unroll
     for (int j = 0; j < YP; j++) {
       const unsigned char* g = (ysrc0[j] && m0 + yrow[j] < (size_t)p.M) ? ysrc0[j] + m0 * p.ldy * 2 : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(base + (YP * wave + j) * 1024), 16, 0, 0);
+      dma16(g, lds_u32(base + (YP * wave + j) * 1024));
     }
 #pragma unroll
     for (int j = 0; j < XP; j++) {
       const unsigned char* g = (xsrc0[j] && m0 + xrow[j] < (size_t)p.M) ? xsrc0[j] + m0 * ldx * 2 : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(base + Y_BYTES + (XP * wave + j) * 1024), 16, 0, 0);
+      dma16(g, lds_u32(base + Y_BYTES + (XP * wave + j) * 1024));
     }
   };
 
