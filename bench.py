@@ -57,6 +57,30 @@ def build(device):
     return dif
 
 
+KERNEL_DESC = {
+    "conv_taps_bf16_kernel": "conv_taps_bf16_kernel<WM, WT, D> (all-taps k5 implicit-GEMM convolution: forward + data-gradient "
+                             "launches of the stride-1 k5 layers, both tile instantiations)",
+    "gemm_fwd_bf16_kernel": "gemm_fwd_bf16_kernel<OutT, BM, BN, WT, D> (LDS-DMA implicit-GEMM conv/linear: forward + "
+                            "data-gradient launches of the 1x1 / strided / linear layers, all tile instantiations)",
+    "gemm_wgrad_taps_bf16_kernel": "gemm_wgrad_taps_bf16_kernel<BO, BC, 5, NQ, D> (all-taps k5 weight gradient)",
+    "gemm_wgrad_bf16_kernel": "gemm_wgrad_bf16_kernel<BO, BC> (per-tap weight gradient)",
+}
+
+
+def load_traffic(kernel, launches_per_step):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
+    in separate runs of this same command by scripts/pmc_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for 16-byte-per-lane reads on gfx950).  None when no PMC summary has been recorded for the kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)["kernels"][kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+    return {"bytes_per_launch": rec["bytes_per_launch"], "fetch_bytes": rec["fetch_bytes"], "write_bytes": rec["write_bytes"],
+            "launches_per_step_in_pmc_run": rec["launches_per_step"], "source": "profiles/pmc_traffic.json (" + rec["command"] + ")"}
+
+
 def cpu_baseline(seconds_budget=30.0):
     """The oracle (plain PyTorch fp32 restatement of the reference path) on this box's host cores, on a bounded
     sample of the same workload: one optimizer step (fwd + bwd + Adam) on 32 of the 256 windows."""
@@ -197,8 +221,9 @@ def main():
 
     if rank == 0:
         summ = timer.summary()
-        dom = "gemm_fwd_bf16_kernel"
+        dom = max((k for k in summ if "gemm" in k or "conv_taps" in k), key=lambda k: summ[k]["ms"])   # dominant kernel
         d = summ[dom]
+        traffic = load_traffic(dom, d["launches"] / args.steps)
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         kernels = {k: {"launches_per_step": v["launches"] / args.steps, "avg_us": 1e3 * v["ms"] / v["launches"],
                        "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
@@ -214,9 +239,9 @@ def main():
                        "step": "loss fwd + bwd + bucketed all-reduce + fused Adam (+EMA every 10)",
                        "launch": "one hipGraph replay per step" if use_graph else "eager"},
             "loss": float(loss),
-            "roofline": {"bound": "mfma", "kernel": "gemm_fwd_bf16_kernel<OutT, BM, BN, WT> (LDS-DMA implicit-GEMM conv/linear: forward + data-gradient launches, all tile instantiations)",
+            "roofline": {"bound": "mfma", "kernel": KERNEL_DESC.get(dom, dom),
                          "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TF,
-                         "traffic": None, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
+                         "traffic": traffic, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                          "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                          "launches_per_step": d["launches"] / args.steps,
                          "timed_on": "an instrumented eager pass of the same K steps right after the timed region "

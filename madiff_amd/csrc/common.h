@@ -24,35 +24,23 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
-// mish(x) = x * tanh(softplus(x)); written via e = exp(-|x|) so it never overflows.
-// tanh(log(1+e^x)) = ((1+e^x)^2 - 1) / ((1+e^x)^2 + 1)
+// mish(x) = x * tanh(softplus(x)).  With t = e^x:  tanh(log(1 + t)) = ((1+t)^2 - 1) / ((1+t)^2 + 1) = p / (p + 2),
+// p = t (t + 2).  x is clamped at 20 before the exponential (t^2 stays far below fp32 overflow; beyond 20 the ratio is
+// 1 to fp32 precision anyway), and for very negative x the ratio degrades gracefully to t.  One v_exp_f32, one
+// v_rcp_f32 (1 ulp) and a handful of FMAs: the IEEE division this replaces cost more than everything else together.
 __device__ __forceinline__ float mish_f(float x) {
-  float e = __expf(-fabsf(x));
-  float num, den;
-  if (x >= 0.f) {            // u = e^x = 1/e : ((1+u)^2-1)/((1+u)^2+1) = (1+2e)/(1+2e+2e^2)
-    num = 1.f + 2.f * e;
-    den = num + 2.f * e * e;
-  } else {                   // u = e : (u^2+2u)/(u^2+2u+2)
-    num = e * e + 2.f * e;
-    den = num + 2.f;
-  }
-  return x * (num / den);
+  const float t = __builtin_amdgcn_exp2f(fminf(x, 20.f) * 1.44269504088896341f);
+  const float p = t * (t + 2.f);
+  return x * p * __builtin_amdgcn_rcpf(p + 2.f);
 }
-// d/dx mish(x) = tanh(sp) + x * sigmoid(x) * (1 - tanh(sp)^2)
+// d/dx mish(x) = th + x * sigmoid(x) * (1 - th^2),  th = p / (p + 2),  1 - th = 2 / (p + 2),  sigmoid = t / (1 + t)
 __device__ __forceinline__ float mish_grad_f(float x) {
-  float e = __expf(-fabsf(x));
-  float num, den, sig;
-  if (x >= 0.f) {
-    num = 1.f + 2.f * e;
-    den = num + 2.f * e * e;
-    sig = 1.f / (1.f + e);
-  } else {
-    num = e * e + 2.f * e;
-    den = num + 2.f;
-    sig = e / (1.f + e);
-  }
-  float th = num / den;
-  return th + x * sig * (1.f - th * th);
+  const float t = __builtin_amdgcn_exp2f(fminf(x, 20.f) * 1.44269504088896341f);
+  const float p = t * (t + 2.f);
+  const float r = __builtin_amdgcn_rcpf(p + 2.f);
+  const float th = p * r;
+  const float sig = t * __builtin_amdgcn_rcpf(1.f + t);
+  return th + x * sig * (2.f * r) * (1.f + th);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -210,11 +210,11 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_vec_kernel(
       }
     const float rstd = rsqrtf(wave_sum(sq) * inv_e + eps);
     if (lane == 0 && mean_out) { mean_out[s] = mean; rstd_out[s] = rstd; }
-    float gm[E], bt[E], rb[E];
+    float gm[E], bt[E], rb[E];                 // z = v * gm + bt with the normalisation folded in
 #pragma unroll
     for (int e = 0; e < E; e++) {
-      gm[e] = gamma[c0 + e];
-      bt[e] = beta[c0 + e];
+      gm[e] = rstd * gamma[c0 + e];
+      bt[e] = beta[c0 + e] - mean * gm[e];
       rb[e] = mode == 1 ? rowbias[(size_t)n * ldrb + c0 + e] : 0.f;
     }
 #pragma unroll
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_vec_kernel(
         if (mode == 2) load_vec<T>(res + row * ldr + c0, o);
 #pragma unroll
         for (int e = 0; e < E; e++) {
-          float z = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+          float z = v[i][e] * gm[e] + bt[e];
           o[e] = mish_f(z) + (mode == 2 ? o[e] : rb[e]);
         }
         store_vec<T>(out + row * ldo + c0, o);
@@ -328,6 +328,286 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_vec_kernel(
   }
 }
 
+// ================================================================================================
+// Row-block path (the one every layer of the real model takes).  A wave owns, for one sequence, ALL T rows of a
+// channel range of CWV 16-byte vectors (a power of two, >= one group): lane = (row r0 = lane / CWV, vector lane % CWV),
+// iteration i covers row r0 + i * (64 / CWV), VPL = ceil(T / (64 / CWV)) iterations.  Every lane keeps the same
+// channel vector for all its rows, adjacent lanes read adjacent 16-byte vectors (full-row coalescing), and a wave
+// covers 1..8 groups, so small slabs (16 channels x 12 steps) no longer leave most lanes idle.  Group statistics are
+// butterfly sums over the lane bits that stay inside a group (low log2(Cg/E) bits of the vector index + the row bits).
+// ================================================================================================
+template <int MASKBITS>
+__device__ __forceinline__ float group_sum(float v, int lowbits, int cwv_log2) {
+  // lanes of one group differ in bits [0, lowbits) and [cwv_log2, 6)
+  for (int b = 0; b < lowbits; b++) v += __shfl_xor(v, 1 << b, 64);
+  for (int b = cwv_log2; b < 6; b++) v += __shfl_xor(v, 1 << b, 64);
+  return v;
+}
+
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void gn_mish_fwd_rb_kernel(
+    const T* __restrict__ y, int ldy, T* __restrict__ out, int ldo, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mean_out, float* __restrict__ rstd_out, int N, int Tn, int C,
+    int G, float eps, int mode, const float* __restrict__ rowbias, int ldrb, const T* __restrict__ res, int ldr,
+    int cwv_log2, int gv_log2) {                 // CWV = 1 << cwv_log2 vectors per wave row, 1 << gv_log2 vectors per group
+  constexpr int E = Vec<T>::E;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int CWV = 1 << cwv_log2, RPI = 64 >> cwv_log2;
+  const int ranges = (C / E) >> cwv_log2;        // channel ranges per sequence
+  const int Cg = C / G;
+  const float inv_e = 1.f / (float)(Tn * Cg);
+  const int cv = lane & (CWV - 1), r0 = lane >> cwv_log2;
+  const long items = (long)N * ranges;
+  for (long it = (long)blockIdx.x * 4 + wave; it < items; it += (long)gridDim.x * 4) {
+    const int n = (int)(it / ranges), rg = (int)(it - (long)n * ranges);
+    const int c0 = ((rg << cwv_log2) + cv) * E;
+    const size_t rbase = (size_t)n * Tn;
+    float v[VPL][E], rs[VPL][E];
+    float sum = 0.f;
+    // every global load of the item is issued up front (one exposed memory latency per item instead of three)
+    float gm[E], bt[E], rb[E];
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      const int r = r0 + i * RPI;
+      if (r < Tn) load_vec<T>(y + (rbase + r) * ldy + c0, v[i]);
+    }
+    if (mode == 2) {
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        const int r = r0 + i * RPI;
+        if (r < Tn) load_vec<T>(res + (rbase + r) * ldr + c0, rs[i]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      gm[e] = gamma[c0 + e];
+      bt[e] = beta[c0 + e];
+      rb[e] = mode == 1 ? rowbias[(size_t)n * ldrb + c0 + e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; i++)
+      if (r0 + i * RPI < Tn) {
+#pragma unroll
+        for (int e = 0; e < E; e++) sum += v[i][e];
+      }
+    const float mean = group_sum<0>(sum, gv_log2, cwv_log2) * inv_e;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++)
+      if (r0 + i * RPI < Tn) {
+#pragma unroll
+        for (int e = 0; e < E; e++) { float d = v[i][e] - mean; sq += d * d; }
+      }
+    const float rstd = rsqrtf(group_sum<0>(sq, gv_log2, cwv_log2) * inv_e + eps);
+    if (mean_out && r0 == 0 && (cv & ((1 << gv_log2) - 1)) == 0) {
+      const int g = c0 / Cg;
+      mean_out[(size_t)n * G + g] = mean;
+      rstd_out[(size_t)n * G + g] = rstd;
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) {              // z = v * gm + bt with the normalisation folded in
+      gm[e] *= rstd;
+      bt[e] -= mean * gm[e];
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      const int r = r0 + i * RPI;
+      if (r < Tn) {
+        float o[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) o[e] = mish_f(v[i][e] * gm[e] + bt[e]) + (mode == 2 ? rs[i][e] : rb[e]);
+        store_vec<T>(out + (rbase + r) * ldo + c0, o);
+      }
+    }
+  }
+}
+
+// grid = (ranges, NB): a workgroup owns one channel range and strides over sequences; every lane keeps its channel
+// vector, so dgamma / dbeta / dbias partial sums stay in registers until the end (then lanes -> waves -> one atomic per
+// channel per workgroup).
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void gn_mish_bwd_rb_kernel(
+    const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd, T* __restrict__ dy, int ldg,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dbias, float* __restrict__ drowbias, int ldrb, int N, int Tn, int C, int G, int cwv_log2,
+    int gv_log2) {
+  constexpr int E = Vec<T>::E;
+  __shared__ float red[4][3][64 * 8];          // [wave][dgamma|dbeta|dbias][channels of the range] (CWV * E <= 512)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int CWV = 1 << cwv_log2, RPI = 64 >> cwv_log2;
+  const int Cg = C / G;
+  const float inv_e = 1.f / (float)(Tn * Cg);
+  const int cv = lane & (CWV - 1), r0 = lane >> cwv_log2;
+  const int c0 = (((int)blockIdx.x << cwv_log2) + cv) * E;
+  const int g = c0 / Cg;
+  float gm[E], bt[E], a_dg[E], a_db[E], a_dbias[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) { gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; a_dg[e] = a_db[e] = a_dbias[e] = 0.f; }
+  for (int n = blockIdx.y * 4 + wave; n < N; n += gridDim.y * 4) {
+    const size_t rbase = (size_t)n * Tn;
+    const float mean = mean_in[(size_t)n * G + g], rstd = rstd_in[(size_t)n * G + g];
+    float xh[VPL][E], dxh[VPL][E], rbs[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) rbs[e] = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      const int r = r0 + i * RPI;
+      if (r < Tn) {
+        float yv[E], go[E];
+        load_vec<T>(y + (rbase + r) * ldy + c0, yv);
+        load_vec<T>(dout + (rbase + r) * ldd + c0, go);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const float x = (yv[e] - mean) * rstd;
+          const float dz = go[e] * mish_grad_f(x * gm[e] + bt[e]);
+          a_dg[e] += dz * x;
+          a_db[e] += dz;
+          rbs[e] += go[e];
+          xh[i][e] = x;
+          dxh[i][e] = dz * gm[e];
+          s1 += dxh[i][e];
+          s2 += dxh[i][e] * x;
+        }
+      }
+    }
+    s1 = group_sum<0>(s1, gv_log2, cwv_log2) * inv_e;
+    s2 = group_sum<0>(s2, gv_log2, cwv_log2) * inv_e;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      const int r = r0 + i * RPI;
+      if (r < Tn) {
+        float o[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          o[e] = rstd * (dxh[i][e] - s1 - xh[i][e] * s2);
+          a_dbias[e] += o[e];
+        }
+        store_vec<T>(dy + (rbase + r) * ldg + c0, o);
+      }
+    }
+    if (drowbias) {   // d temb[n, c] = sum_t dout: reduce over the lanes that share this channel vector (the row bits)
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        float r = rbs[e];
+        for (int b = cwv_log2; b < 6; b++) r += __shfl_xor(r, 1 << b, 64);
+        rbs[e] = r;
+      }
+      if (r0 == 0) {
+#pragma unroll
+        for (int e = 0; e < E; e++) drowbias[(size_t)n * ldrb + c0 + e] = rbs[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    float a = a_dg[e], b = a_db[e], c = a_dbias[e];
+    for (int bb = cwv_log2; bb < 6; bb++) { a += __shfl_xor(a, 1 << bb, 64); b += __shfl_xor(b, 1 << bb, 64); c += __shfl_xor(c, 1 << bb, 64); }
+    if (r0 == 0) { red[wave][0][cv * E + e] = a; red[wave][1][cv * E + e] = b; red[wave][2][cv * E + e] = c; }
+  }
+  __syncthreads();
+  const int CW = CWV * E, cbase = ((int)blockIdx.x << cwv_log2) * E;
+  for (int i = threadIdx.x; i < 3 * CW; i += 256) {
+    const int q = i / CW, c = i - q * CW;
+    const float a = red[0][q][c] + red[1][q][c] + red[2][q][c] + red[3][q][c];
+    float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : dbias);
+    if (dst) atomicAdd(&dst[cbase + c], a);
+  }
+}
+
+// Geometry of the row-block path: vectors per wave row (cwv_log2), vectors per group (gv_log2), iterations (vpl).
+// Returns 0 when the layer is not covered (the one-slab-per-wave kernels above take it).
+static int rb_path(int dtype, int T, int C, int Cpad, int G, int* cwv_log2, int* gv_log2, int* vpl) {
+  const int E = dtype == MADIFF_BF16 ? 8 : 4;
+  const int Cg = C / G;
+  if (Cpad != C || Cg % E) return 0;
+  const int gv = Cg / E, rowv = C / E;
+  if ((gv & (gv - 1)) || gv > 64 || (rowv & (rowv - 1))) return 0;
+  int best = -1, best_vpl = 0, best_waste = 1 << 30;
+  for (int l = 0; (1 << l) <= 64 && (1 << l) <= rowv; l++) {
+    if ((1 << l) < gv) continue;
+    const int rpi = 64 >> l, v = (T + rpi - 1) / rpi;
+    if (v > 8) continue;
+    const int waste = v * rpi - T;                // idle row slots per wave
+    // least padding first, then the iteration count closest to 4 (enough loads in flight, still plenty of waves)
+    static int pref = -1;
+    if (pref < 0) { const char* e = getenv("MADIFF_GN_VPL"); pref = e ? atoi(e) : 4; }
+    const int score = waste * 16 + (v > pref ? v - pref : pref - v);
+    if (score < best_waste) { best_waste = score; best = l; best_vpl = v; }
+  }
+  if (best < 0) return 0;
+  int gl = 0;
+  while ((1 << gl) < gv) gl++;
+  *cwv_log2 = best; *gv_log2 = gl; *vpl = best_vpl;
+  return 1;
+}
+
+#define GN_RB_SWITCH(VPL_, CALL)  \
+  switch (VPL_) {                 \
+    case 1: { CALL(1); break; }   \
+    case 2: { CALL(2); break; }   \
+    case 3: { CALL(3); break; }   \
+    case 4: { CALL(4); break; }   \
+    case 5: { CALL(5); break; }   \
+    case 6: { CALL(6); break; }   \
+    case 7: { CALL(7); break; }   \
+    default: { CALL(8); break; }  \
+  }
+
+static int gn_fwd_rb(int dtype, const void* y, int ldy, void* out, int ldo, const float* gamma, const float* beta, float* mean,
+                     float* rstd, int N, int T, int C, int Cpad, int G, float eps, int mode, const float* rowbias, int ldrb,
+                     const void* res, int ldr, hipStream_t stream) {
+  int cl, gl, vpl;
+  const int E = dtype == MADIFF_BF16 ? 8 : 4;
+  if (!rb_path(dtype, T, C, Cpad, G, &cl, &gl, &vpl) || ldy % E || ldo % E || (mode == 2 && ldr % E) ||
+      ((size_t)y % 16) || ((size_t)out % 16) || (mode == 2 && ((size_t)res % 16)))
+    return 1;
+  const long items = (long)N * ((C / E) >> cl);
+  const int blocks = (int)((items + 3) / 4 < 8192 ? (items + 3) / 4 : 8192);
+#define GN_FWD_CALL(V)                                                                                                  \
+  if (dtype == MADIFF_BF16)                                                                                             \
+    hipLaunchKernelGGL((gn_mish_fwd_rb_kernel<bf16_t, V>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)y, ldy,   \
+                       (bf16_t*)out, ldo, gamma, beta, mean, rstd, N, T, C, G, eps, mode, rowbias, ldrb,               \
+                       (const bf16_t*)res, ldr, cl, gl);                                                                \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((gn_mish_fwd_rb_kernel<float, V>), dim3(blocks), dim3(256), 0, stream, (const float*)y, ldy,     \
+                       (float*)out, ldo, gamma, beta, mean, rstd, N, T, C, G, eps, mode, rowbias, ldrb,                \
+                       (const float*)res, ldr, cl, gl)
+  GN_RB_SWITCH(vpl, GN_FWD_CALL)
+#undef GN_FWD_CALL
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+static int gn_bwd_rb(int dtype, const void* y, int ldy, const void* dout, int ldd, void* dy, int ldg, const float* gamma,
+                     const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias,
+                     float* drowbias, int ldrb, int N, int T, int C, int Cpad, int G, hipStream_t stream) {
+  int cl, gl, vpl;
+  const int E = dtype == MADIFF_BF16 ? 8 : 4;
+  if (!rb_path(dtype, T, C, Cpad, G, &cl, &gl, &vpl) || ldy % E || ldd % E || ldg % E || ((size_t)y % 16) ||
+      ((size_t)dout % 16) || ((size_t)dy % 16))
+    return 1;
+  const int ranges = (C / E) >> cl;
+  static int wgs = -1;
+  if (wgs < 0) { const char* e = getenv("MADIFF_GN_BWD_WGS"); wgs = e ? atoi(e) : 1024; }
+  int nb = wgs / ranges;                        // workgroups in flight (each ends with one atomic per channel)
+  if (nb > (N + 3) / 4) nb = (N + 3) / 4;
+  if (nb < 1) nb = 1;
+  dim3 grid(ranges, nb);
+#define GN_BWD_CALL(V)                                                                                                  \
+  if (dtype == MADIFF_BF16)                                                                                             \
+    hipLaunchKernelGGL((gn_mish_bwd_rb_kernel<bf16_t, V>), grid, dim3(256), 0, stream, (const bf16_t*)y, ldy,           \
+                       (const bf16_t*)dout, ldd, (bf16_t*)dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias,      \
+                       drowbias, ldrb, N, T, C, G, cl, gl);                                                             \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((gn_mish_bwd_rb_kernel<float, V>), grid, dim3(256), 0, stream, (const float*)y, ldy,             \
+                       (const float*)dout, ldd, (float*)dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias,        \
+                       drowbias, ldrb, N, T, C, G, cl, gl)
+  GN_RB_SWITCH(vpl, GN_BWD_CALL)
+#undef GN_BWD_CALL
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 static int vec_path(int dtype, int T, int C, int Cpad, int G, int* vpr_log2) {
   const int E = dtype == MADIFF_BF16 ? 8 : 4;
   const int Cg = C / G;
@@ -382,9 +662,12 @@ extern "C" int madiff_gn_mish_fwd(int dtype, const void* y, int ldy, void* out, 
       (mode == 1 && (!rowbias || ldrb < C)) || (mode == 2 && (!res || ldr < C)) || mode < 0 || mode > 2)
     return -1;
   {
-    int rc = madiff_gn_fwd_vec(dtype, y, ldy, out, ldo, gamma, beta, mean, rstd, N, T, C, Cpad, G, eps, mode, rowbias, ldrb,
-                               res, ldr, stream);
-    if (rc <= 0) return rc;      // 0 = launched, <0 = error, 1 = shape not covered by the vector path
+    int rc = gn_fwd_rb(dtype, y, ldy, out, ldo, gamma, beta, mean, rstd, N, T, C, Cpad, G, eps, mode, rowbias, ldrb, res, ldr,
+                       stream);
+    if (rc <= 0) return rc;      // 0 = launched, <0 = error, 1 = shape not covered by the row-block path
+    rc = madiff_gn_fwd_vec(dtype, y, ldy, out, ldo, gamma, beta, mean, rstd, N, T, C, Cpad, G, eps, mode, rowbias, ldrb,
+                           res, ldr, stream);
+    if (rc <= 0) return rc;      // ... by the one-slab-per-wave vector path
   }
   long slabs = (long)N * G;
   int blocks = (int)((slabs + 3) / 4 < 8192 ? (slabs + 3) / 4 : 8192);
@@ -411,8 +694,11 @@ extern "C" int madiff_gn_mish_bwd(int dtype, const void* y, int ldy, const void*
       ldg < Cpad || (drowbias && ldrb < C))
     return -1;
   {
-    int rc = madiff_gn_bwd_vec(dtype, y, ldy, dout, ldd, dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias, drowbias,
-                               ldrb, N, T, C, Cpad, G, stream);
+    int rc = gn_bwd_rb(dtype, y, ldy, dout, ldd, dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias, drowbias, ldrb, N, T,
+                       C, Cpad, G, stream);
+    if (rc <= 0) return rc;
+    rc = madiff_gn_bwd_vec(dtype, y, ldy, dout, ldd, dy, ldg, gamma, beta, mean, rstd, dgamma, dbeta, dbias, drowbias,
+                           ldrb, N, T, C, Cpad, G, stream);
     if (rc <= 0) return rc;
   }
   int nb = (N + 3) / 4;

@@ -251,14 +251,22 @@ def _gemm_label(cin: int, csplit: int, out_f32: bool) -> str:
 
 
 def _timed(name: str, flops: float, launch):
+    """launch() may return the name of the kernel it actually dispatched to (overrides `name`)."""
     if TIMER is None:
         launch()
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    launch()
+    used = launch()
     e1.record()
-    TIMER.records.append((name, flops, e0, e1))
+    TIMER.records.append((used if isinstance(used, str) else name, flops, e0, e1))
+
+
+FIRST_TAPS_TILE = 14      # variant ids >= this are the all-taps k5 kernel (csrc/conv_taps_bf16.hip)
+
+
+def _tile_label(tile):
+    return "conv_taps_bf16_kernel" if isinstance(tile, int) and tile >= FIRST_TAPS_TILE else None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -309,8 +317,11 @@ def _gemm(x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, tr, W, nout, npad,
     tile = _tuned_tile(("fwd", M, cin, spec.taps, npad, t_out, spec.stride, tr, out_f32, x2 is not None,
                         rowbias is not None, x.stride(0), out.stride(0)),
                        lib.tiles(), launch) if dma else -1
-    if launch(tile) and launch(-1):      # (a tuned variant may not cover a same-shaped layer with other alignments)
-        raise RuntimeError(f"madiff_gemm_fwd: no kernel variant covers this layer")
+    if launch(tile):                     # (a tuned variant may not cover a same-shaped layer with other alignments)
+        tile = -1
+        if launch(-1):
+            raise RuntimeError("madiff_gemm_fwd: no kernel variant covers this layer")
+    return _tile_label(tile)
 
 
 def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncols, ncols_pad):
@@ -339,8 +350,11 @@ def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncol
             return None
         if ksplit <= 1:
             _tuned_tile(sig, lib.tiles(wt=True), launch)   # remember the fastest variant (no-op under capture / if disabled)
-    elif launch(tile) and launch(-1):
-        raise RuntimeError("madiff_gemm_dgrad_wt: no kernel variant covers this layer")
+    elif launch(tile):
+        tile = -1
+        if launch(-1):
+            raise RuntimeError("madiff_gemm_dgrad_wt: no kernel variant covers this layer")
+    _dgrad_wt.last_label = _tile_label(tile)
     return gx.to(act_dtype()) if ksplit > 1 else gx
 
 
@@ -382,6 +396,7 @@ def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, acc
     if cfg is None:
         cfg = (-1, 0)
     launch(dW, accumulate, cfg[0], cfg[1])
+    return "gemm_wgrad_taps_bf16_kernel" if (cfg[0] >= 4 and _PRECISION == "bf16") else None
 
 
 def pack_traj(x: torch.Tensor, fpad: int, noise=None, t=None, sqrt_ac=None, sqrt_1mac=None, cond=None, mask=None,
@@ -570,6 +585,7 @@ def _conv_forward(x, x2, rowbias, spec: ConvSpec, t_in: int, act: int, perm, wei
     g.flops = 2.0 * (M_in if spec.tr else M) * osum * I * spec.taps
     _timed(_gemm_label(cin, c1, out.dtype == torch.float32), g.flops,
            lambda: _gemm(x, x2, c1, M, cin, spec, t_out, t_in, spec.tr, W, osum, npad, bias, rowbias, out, act, perm))
+    # (_gemm returns the dispatched kernel's name when it is not the default LDS-DMA kernel)
     g.spec, g.t_in, g.t_out, g.act, g.perm = spec, t_in, t_out, act, perm
     g.dims, g.osum, g.cin, g.c1, g.n_seq, g.I = dims, osum, cin, c1, n_seq, I
     return out, g
@@ -596,7 +612,9 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
             res = [None]
 
             def run_wt():
+                _dgrad_wt.last_label = None
                 res[0] = _dgrad_wt(dy, M_in, npad, spec, t_in, t_out, Wf, cin, row0, rows, pad32(rows))
+                return _dgrad_wt.last_label
 
             if Wf is not None:
                 _timed("gemm_fwd_bf16_kernel", g.flops * rows / I, run_wt)
