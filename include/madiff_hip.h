@@ -138,6 +138,10 @@ int madiff_act_bwd(int dtype, int kind, const void* ref, const void* dy, void* d
 
 /* Bias gradients: out[c] += sum_m x[m, c] (caller zeroes) and per-sequence sums out[n, c] = sum_t x[(n,t), c]. */
 int madiff_colsum(int dtype, const void* x, int ld, float* out, long M, int C, madiff_stream_t stream);
+/* Same sums for a GROUP of layers that share one output-gradient matrix (q/k/v projections, the 21 Linear(Mish(t_emb))
+ * of temporal.py:173-176 / :69-80 evaluated as one GEMM): column c is added to *table[c] (device array of C float
+ * addresses, one per gradient element of the members' biases).  Returns 1 if the layout is not 16-byte vectorisable. */
+int madiff_colsum_scatter(int dtype, const void* x, int ld, float* const* table, long M, int C, madiff_stream_t stream);
 int madiff_seqsum(int dtype, const void* x, int ld, float* out, int ldo, long N, int T, int C, madiff_stream_t stream);
 
 /* Fused Adam (torch.optim.Adam defaults, diffuser/utils/training.py:109,154) + EMA (training.py:20-39) over one flat

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 }
 // vectorised colsum (ld and C multiples of the 16-byte vector): 32 column vectors x 8 rows per block
 template <typename T, int E>
-__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, long M, int C) {
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, long M, int C,
+                                                            float* const* __restrict__ tab = nullptr) {
   __shared__ float red[8][32 * E];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c0 = (blockIdx.x * 32 + tx) * E;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; r++) s += red[r][i];
-      atomicAdd(&out[c], s);
+      atomicAdd(tab ? tab[c] : &out[c], s);       // tab: one destination address per column (a group of bias gradients)
     }
   }
 }
@@ -379,12 +380,32 @@ extern "C" int madiff_act_bwd(int dtype, int kind, const void* ref, const void* 
   return 0;
 }
 
+// Column sums of a GROUP of layers' output gradient, each column added (atomically) to its own destination:
+// table[c] = address of the gradient element of column c (device array of C pointers).  Replaces one temporary, one
+// reduction and one `grad += slice` pass per member of a q/k/v or time-MLP bundle.  Requires the vector layout
+// (ld, C multiples of 8 (bf16) / 4 (fp32), 16-byte aligned x); returns 1 otherwise.
+extern "C" int madiff_colsum_scatter(int dtype, const void* x, int ld, float* const* table, long M, int C, hipStream_t stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (ld < C || !table) return -1;
+  const int E = dtype == MADIFF_BF16 ? 8 : 4;
+  if (ld % E || C % E || (size_t)x % 16) return 1;
+  int rbv = (int)((M + 63) / 64);
+  if (rbv > 128) rbv = 128;
+  dim3 g((C / E + 31) / 32, rbv);
+  if (dtype == MADIFF_BF16)
+    hipLaunchKernelGGL((colsum_vec_kernel<bf16_t, 8>), g, dim3(256), 0, stream, (const bf16_t*)x, ld, nullptr, M, C, table);
+  else
+    hipLaunchKernelGGL((colsum_vec_kernel<float, 4>), g, dim3(256), 0, stream, (const float*)x, ld, nullptr, M, C, table);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int madiff_colsum(int dtype, const void* x, int ld, float* out, long M, int C, hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;
   if (ld < C) return -1;
   {
     const int E = dtype == MADIFF_BF16 ? 8 : 4;
-    if (ld % E == 0 && C % E == 0) {
+    if (ld % E == 0 && C % E == 0 && (size_t)x % 16 == 0) {
       int rbv = (int)((M + 63) / 64);
       if (rbv > 128) rbv = 128;
       if (rbv < 1) rbv = 1;

@@ -13,6 +13,8 @@ Differences that are additions, not changes of behaviour:
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional
 
 import numpy as np
@@ -63,6 +65,9 @@ class InvDynMLP(nn.Sequential):
         if self.softmax:
             h = torch.softmax(h, dim=-1)
         return h.reshape(*lead, self.out_dim)
+
+
+INV_SIDE_STREAM = os.environ.get("MADIFF_INV_SIDE_STREAM", "1") != "0"
 
 
 class WeightedStateL2(nn.Module):
@@ -324,6 +329,16 @@ class GaussianDiffusion(nn.Module):
     def loss(self, x, cond, loss_masks, attention_masks=None, returns=None, env_ts=None, states=None,
              legal_actions=None, t=None, noise=None, dropout_mask=None):
         """diffusion.py:438-496; called as ``loss(**batch)``."""
+        # The inverse-dynamics branch shares nothing with the denoiser branch until the final sum, and it is ~50 small
+        # launches: on the GPU it runs on a second stream (forward here, backward there too, since autograd replays
+        # a node on its forward stream), i.e. as a parallel branch of the captured train-step graph.
+        side = None
+        if x.is_cuda and not self.train_only_inv and INV_SIDE_STREAM:
+            cur = torch.cuda.current_stream()
+            side = ops.aux_stream(x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                inv_loss, inv_info = self.compute_inv_loss(x, loss_masks, legal_actions)
         if self.train_only_inv:
             info = {}
         else:
@@ -333,7 +348,13 @@ class GaussianDiffusion(nn.Module):
                                   device=x.device).long()
             diffuse_loss, info = self.p_losses(x[..., self.action_dim:], cond, t, loss_masks, attention_masks, returns,
                                                env_ts, states, noise=noise, dropout_mask=dropout_mask)
-        inv_loss, inv_info = self.compute_inv_loss(x, loss_masks, legal_actions)
+        if side is None:
+            inv_loss, inv_info = self.compute_inv_loss(x, loss_masks, legal_actions)
+        else:
+            cur.wait_stream(side)
+            for v in [inv_loss, *inv_info.values()]:
+                if torch.is_tensor(v):
+                    v.record_stream(cur)
         info = {**info, **inv_info}
         info["inv_loss"] = inv_loss
         if self.train_only_inv:

@@ -43,6 +43,7 @@ _SIGS = {
     "madiff_act_fwd": [_i, _i, _vp, _vp, _l, _vp],
     "madiff_act_bwd": [_i, _i, _vp, _vp, _vp, _l, _vp],
     "madiff_colsum": [_i, _vp, _i, _vp, _l, _i, _vp],
+    "madiff_colsum_scatter": [_i, _vp, _i, _vp, _l, _i, _vp],
     "madiff_seqsum": [_i, _vp, _i, _vp, _i, _l, _i, _i, _vp],
     "madiff_adam_ema": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _i, _vp],
 }

@@ -51,6 +51,19 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+AUX_STREAMS: dict = {}
+
+
+def aux_stream(device) -> "torch.cuda.Stream":
+    """The one auxiliary stream per device on which independent branches of a step are issued (the data-parallel
+    optimizer waits on it, besides the current stream, before it reduces a gradient bucket)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = AUX_STREAMS.get(key)
+    if st is None:
+        st = AUX_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -117,7 +130,19 @@ _MULTI = {"sig": None, "table": None, "n": 0, "blocks": 0}
 
 
 class _PackEntry:
-    __slots__ = ("vers", "buf", "refs", "jobs")
+    __slots__ = ("vers", "buf", "refs", "jobs", "ready")     # ready: (event, stream id) of the launch that last wrote buf
+
+
+def _mark_ready(entries):
+    """Entries were just (re)packed on the current stream: a reader on another stream (a parallel branch of the step,
+    ops.aux_stream) has to wait for that launch, which _packed() arranges through this event."""
+    if not entries or not entries[0].buf.is_cuda:
+        return
+    ev = torch.cuda.Event()
+    ev.record()
+    sid = torch.cuda.current_stream().cuda_stream
+    for e in entries:
+        e.ready = (ev, sid)
 
 
 def _entry_vers(weights):
@@ -160,6 +185,7 @@ def _refresh_stale(trigger_key):
         for j in ent.jobs(ws):
             lib.call("madiff_pack_weight", _dt(), j[0], j[1], j[2], j[3], j[4], j[5], j[6], j[7], j[8], j[9], _stream())
         ent.vers = v
+        _mark_ready([ent])
         return
     rows, blk = [], 0
     for key, ent, ws, v in stale:
@@ -173,6 +199,7 @@ def _refresh_stale(trigger_key):
             for j in ent.jobs(ws):
                 lib.call("madiff_pack_weight", _dt(), j[0], j[1], j[2], j[3], j[4], j[5], j[6], j[7], j[8], j[9], _stream())
             ent.vers = v
+        _mark_ready([e_[1] for e_ in stale])
         return
     if _MULTI["sig"] != sig:
         dev = stale[0][1].buf.device
@@ -181,6 +208,7 @@ def _refresh_stale(trigger_key):
     lib.call("madiff_pack_weights_multi", _dt(), _MULTI["table"].data_ptr(), _MULTI["n"], _MULTI["blocks"], _stream())
     for key, ent, ws, v in stale:
         ent.vers = v
+    _mark_ready([e_[1] for e_ in stale])
 
 
 def _packed(weights: Sequence[torch.Tensor], spec: ConvSpec, backward: bool) -> torch.Tensor:
@@ -204,12 +232,16 @@ def _packed(weights: Sequence[torch.Tensor], spec: ConvSpec, backward: bool) -> 
         ent = _PackEntry()
         ent.buf = torch.zeros(shape, dtype=act_dtype(), device=weights[0].device)
         ent.vers = None
+        ent.ready = None
         ent.refs = tuple(weakref.ref(w, lambda _r, k=key: _PACK_CACHE.pop(k, None)) for w in weights)
         buf = ent.buf
         ent.jobs = lambda ws, spec=spec, backward=backward, buf=buf: _pack_jobs(ws, spec, backward, buf)
         _PACK_CACHE[key] = ent
     if ent.vers != _entry_vers(weights):
         _refresh_stale(key)
+    rd = ent.ready
+    if rd is not None and rd[1] != torch.cuda.current_stream().cuda_stream:
+        torch.cuda.current_stream().wait_event(rd[0])
     return ent.buf
 
 
@@ -445,6 +477,7 @@ class GradSink:
         self.slots = {}          # id(param) -> (weakref, offset, O, K, kind, taps)
         self.shadow_state = {}   # id(param) -> (param._version, _EPOCH_EXT) at which the bf16 shadow was in sync
         self._groups = {}
+        self._bias_tables = {}
 
     def register(self, param, view):
         assert view.dtype == torch.float32 and view.shape == param.shape
@@ -510,6 +543,24 @@ class GradSink:
         lib.call("madiff_pack_weight", lib.BF16, w.data_ptr(), self.flat_p16.data_ptr() + 2 * off, O, I, taps, so, si, st,
                  K // taps, 0, _stream())
         self.shadow_state[id(w)] = (w._version, _EPOCH_EXT)
+
+    def bias_table(self, biases, device):
+        """Device array of one gradient-element address per output column of a bias group (built on first use, outside
+        graph capture: it needs a host-to-device copy); None when it cannot be built now."""
+        key = tuple(id(b) for b in biases)
+        ent = self._bias_tables.get(key)
+        if ent is not None and all(r() is b for r, b in zip(ent[0], biases)):
+            return ent[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        addrs = []
+        for b in biases:
+            v = self.get(b)
+            assert v.is_contiguous()
+            addrs += [v.data_ptr() + 4 * i for i in range(v.numel())]
+        tab = torch.tensor(addrs, dtype=torch.int64).to(device)
+        self._bias_tables[key] = (tuple(weakref.ref(b) for b in biases), tab)
+        return tab
 
     def grad_matrix(self, weights, spec):
         if self.flat_g is None:
@@ -633,6 +684,17 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
         if x2 is not None:
             dx2 = grads[1]
     gw: List[Optional[torch.Tensor]] = [None] * len(weights)
+    gw, gb = _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw)
+    if need_rb:
+        drb = torch.empty(n_seq, osum, dtype=torch.float32, device=dy.device)
+        lib.call("madiff_seqsum", _dt(), dy.data_ptr(), dy.stride(0), drb.data_ptr(), drb.stride(0), n_seq, t_out,
+                 osum, _stream())
+    return dx, dx2, drb, gw, gb
+
+
+def _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
+    spec, t_in, t_out, osum, cin, c1, n_seq, I = g.spec, g.t_in, g.t_out, g.osum, g.cin, g.c1, g.n_seq, g.I
+    M = n_seq * t_out
     if any(need_w):
         wlabel = "gemm_wgrad_bf16_kernel" if _PRECISION == "bf16" else "gemm_wgrad_kernel<float>"
         gm = SINK.grad_matrix(weights, spec) if (SINK is not None and all(need_w)) else None
@@ -663,6 +725,19 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
             view = _sink_view(biases[0])       # colsum accumulates atomically: add straight into the live gradient
             lib.call("madiff_colsum", _dt(), dy.data_ptr(), dy.stride(0), view.data_ptr(), M, osum, _stream())
             SINK.done(biases[0])
+        elif all(_sink_view(b) is not None for b in biases):
+            # a group (q/k/v, the time-MLP bundle): one column-slice reduction per member, each straight into its live
+            # gradient (no temporary, no `grad += new` pass per member)
+            tab = SINK.bias_table(biases, dy.device)
+            if tab is None or lib.call_rc("madiff_colsum_scatter", _dt(), dy.data_ptr(), dy.stride(0), tab.data_ptr(), M,
+                                          osum, _stream()):
+                off, es = 0, dy.element_size()
+                for b, (O, *_r) in zip(biases, g.dims):
+                    lib.call("madiff_colsum", _dt(), dy.data_ptr() + off * es, dy.stride(0), _sink_view(b).data_ptr(), M,
+                             O, _stream())
+                    off += O
+            for b in biases:
+                SINK.done(b)
         else:
             db = torch.zeros(osum, dtype=torch.float32, device=dy.device)
             lib.call("madiff_colsum", _dt(), dy.data_ptr(), dy.stride(0), db.data_ptr(), M, osum, _stream())
@@ -670,11 +745,7 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
             for i, (O, *_r) in enumerate(g.dims):
                 gb[i] = db[off:off + O]
                 off += O
-    if need_rb:
-        drb = torch.empty(n_seq, osum, dtype=torch.float32, device=dy.device)
-        lib.call("madiff_seqsum", _dt(), dy.data_ptr(), dy.stride(0), drb.data_ptr(), drb.stride(0), n_seq, t_out,
-                 osum, _stream())
-    return dx, dx2, drb, gw, gb
+    return gw, gb
 
 
 class ConvGemm(torch.autograd.Function):

@@ -17,6 +17,7 @@ all-reduced on a side stream as soon as all of its gradients of the last micro-b
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -180,6 +181,8 @@ class FlatAdamEMA:
         g = self.flat_g[b["lo"]:b["hi"]]
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
+            for st in ops.AUX_STREAMS.values():      # members of the bucket may have been produced on a side branch
+                self._comm_stream.wait_stream(st)
             with torch.cuda.stream(self._comm_stream):
                 b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         else:
@@ -223,6 +226,9 @@ class FlatAdamEMA:
         first = self.flat_p is None
         if first:
             self._materialise()
+        if self.flat_p.is_cuda:                      # join the parallel branches of the step (ops.aux_stream)
+            for st in ops.AUX_STREAMS.values():
+                torch.cuda.current_stream().wait_stream(st)
         self._finish_allreduce()
         self.step_count += 1
         b1, b2 = self.betas

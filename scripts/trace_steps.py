@@ -1,18 +1,19 @@
 """Per-step breakdown from a rocprofv3 kernel trace: takes the LAST `nsteps` optimizer steps (delimited by the
 adam_ema_kernel dispatches), and prints, per (kernel, grid) bucket, launches per step, average duration and share, plus
 GPU busy time vs wall time per step (the difference is launch gaps / host-bound time).
-usage: python scripts/trace_steps.py <dir with *_kernel_trace.csv> [nsteps=5] [topN=40]"""
+usage: python scripts/trace_steps.py <dir with *_kernel_trace.csv> [nsteps=5] [topN=40] [skip_last_steps=0]"""
 import csv, glob, sys, collections, re
 
 d = sys.argv[1]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # ignore the last `skip` steps (bench.py's instrumented eager pass)
 f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [i for i, r in enumerate(rows) if "adam_ema_kernel" in r["Kernel_Name"]]
-assert len(adam) > nsteps, "not enough optimizer steps in the trace"
-lo, hi = adam[-nsteps - 1] + 1, adam[-1] + 1
+assert len(adam) > nsteps + skip, "not enough optimizer steps in the trace"
+lo, hi = adam[-nsteps - 1 - skip] + 1, adam[-1 - skip] + 1
 sel = rows[lo:hi]
 wall = (int(sel[-1]["End_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"])) / 1e3 / nsteps
 agg = collections.OrderedDict()
