@@ -139,8 +139,10 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    force_dp = os.environ.get("MADIFF_FORCE_DP") == "1"      # rehearse the data-parallel step in a 1-rank RCCL group
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from madiff_amd import ops
@@ -149,7 +151,7 @@ def main():
     torch.manual_seed(0)
     dif = build(device)
     ema = copy.deepcopy(dif)
-    opt = FlatAdamEMA(dif, ema, lr=2e-4, ema_decay=0.995)
+    opt = FlatAdamEMA(dif, ema, lr=2e-4, ema_decay=0.995, bucket_mb=32.0)
     opt.broadcast_parameters(0)
     batch = synthetic_batch(BATCH, device, seed=rank)
 
@@ -160,10 +162,25 @@ def main():
 
     for i in range(max(args.warmup, 2)):
         train_step(dif, opt, [batch], do_ema=1)
-    # single process: the whole step (loss fwd, bwd, fused Adam/EMA) is one captured hipGraph, replayed per step; the
-    # data-parallel job keeps the eager step whose bucketed all-reduce overlaps backward
-    use_graph = world == 1 and not args.no_graph
-    graphed = GraphedTrainStep(dif, opt, batch) if use_graph else None
+    # single process: the whole step (loss fwd, bwd, fused Adam/EMA) is one captured hipGraph, replayed per step.
+    # data parallel: the graph holds forward + backward with one graph-external event per gradient bucket; the RCCL
+    # all-reduces run eagerly on the communication stream behind those events (overlapping the replayed backward), then
+    # the fused Adam.  If capturing fails the job falls back to the eager step (same arithmetic).
+    use_graph = not args.no_graph
+    graphed = None
+    if use_graph:
+        try:
+            graphed = GraphedTrainStep(dif, opt, batch)
+        except Exception as e:                       # noqa: BLE001
+            if world == 1 and not force_dp:
+                raise
+            print(f"[rank {rank}] graph capture of the data-parallel step failed ({e!r}); using the eager step", flush=True)
+            use_graph = False
+    if world > 1:                                    # every rank must take the same path
+        flag = torch.tensor([1 if graphed is not None else 0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            graphed, use_graph = None, False
 
     def one_step(i):
         ema_mode = 1 if (i % 10 == 9) else 0
@@ -237,7 +254,9 @@ def main():
                                    "dim 128 x [1,4,8], batch 256 per GPU (BASELINE.json configs[1])",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}",
                        "step": "loss fwd + bwd + bucketed all-reduce + fused Adam (+EMA every 10)",
-                       "launch": "one hipGraph replay per step" if use_graph else "eager"},
+                       "launch": ("one hipGraph replay per step" if not opt.dp else
+                                  "hipGraph replay of fwd+bwd, bucketed RCCL all-reduce behind graph-external events, eager "
+                                  "fused Adam") if use_graph else "eager"},
             "loss": float(loss),
             "roofline": {"bound": "mfma", "kernel": KERNEL_DESC.get(dom, dom),
                          "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TF,
@@ -253,7 +272,7 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

@@ -31,6 +31,15 @@ typedef void* madiff_stream_t; /* hipStream_t */
 int madiff_version(void);
 const char* madiff_arch(void);
 
+/* Graph-external events (no counterpart in the reference, which has neither graphs nor data parallelism): a record
+ * issued on a capturing stream becomes an event-record node of the hipGraph, so a stream outside the graph (the RCCL
+ * communication stream of madiff_amd/trainer.py) can wait for "gradient bucket b is complete" inside a replayed
+ * backward pass.  Host-side helpers only: they launch nothing. */
+int madiff_event_create(void** event_out);
+int madiff_event_destroy(void* event);
+int madiff_event_record_external(void* event, madiff_stream_t stream);
+int madiff_stream_wait_event(madiff_stream_t stream, void* event);
+
 /* Implicit-GEMM convolution / linear:
  *   C[m, o] = act( sum_{tap, c} X[src(m, tap), c] * W[o, tap*Cin + c] + bias[o] + rowbias[m / T_out, o] )
  * src(m = (n, t), tap): tr == 0: t_in = t*stride + tap - pad;  tr == 1: t_in = (t + pad - tap) / stride when divisible;

@@ -459,5 +459,44 @@ extern "C" int madiff_adam_ema(float* p, float* g, float* m, float* v, float* em
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Graph-external events: a point inside a captured (hipGraph) train step that streams OUTSIDE the graph can wait on.
+// The data-parallel step replays backward from a graph and starts each gradient bucket's RCCL all-reduce on a
+// communication stream as soon as the bucket's last gradient kernel has run, without putting any collective into the
+// graph.  torch's own external events are disabled on ROCm builds, hence these four thin wrappers.
+// ------------------------------------------------------------------------------------------------
+extern "C" int madiff_event_create(void** event_out) {
+  if (!event_out) return -1;
+  hipEvent_t e;
+  hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  if (rc != hipSuccess) return (int)rc;
+  *event_out = (void*)e;
+  return 0;
+}
+extern "C" int madiff_event_destroy(void* event) { return event ? (int)hipEventDestroy((hipEvent_t)event) : 0; }
+// On a capturing stream this adds an event-record NODE to the graph (executed at every replay); on an ordinary stream it
+// is a plain hipEventRecord.
+extern "C" int madiff_event_record_external(void* event, hipStream_t stream) {
+  if (!event) return -1;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  hipError_t rc = hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, &deps, &ndeps);
+  if (rc != hipSuccess) return (int)rc;
+  if (st != hipStreamCaptureStatusActive) return (int)hipEventRecord((hipEvent_t)event, stream);
+  // (hipEventRecordWithFlags(.., hipEventRecordExternal) is rejected by this runtime: add the node by hand and make it
+  // the capturing stream's new dependency frontier, which is what the flag stands for)
+  hipGraphNode_t node;
+  rc = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, (hipEvent_t)event);
+  if (rc != hipSuccess) return (int)rc;
+  return (int)hipStreamUpdateCaptureDependencies(stream, &node, 1, hipStreamSetCaptureDependencies);
+}
+extern "C" int madiff_stream_wait_event(hipStream_t stream, void* event) {
+  if (!event) return -1;
+  return (int)hipStreamWaitEvent(stream, (hipEvent_t)event, 0);
+}
+
 extern "C" int madiff_version(void) { return 1; }
 extern "C" const char* madiff_arch(void) { return "gfx950"; }

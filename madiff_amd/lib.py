@@ -20,6 +20,10 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
     "madiff_gemm_fwd": [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i,
                         _vp, _i, _i, _i, _i, _i, _vp],
+    "madiff_event_create": [_vp],
+    "madiff_event_destroy": [_vp],
+    "madiff_event_record_external": [_vp, _vp],
+    "madiff_stream_wait_event": [_vp, _vp],
     "madiff_gemm_tile_count": [],
     "madiff_gemm_tile_info": [_i, _vp, _vp, _vp],
     "madiff_gemm_dgrad_wt": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],

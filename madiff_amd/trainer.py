@@ -36,6 +36,10 @@ class FlatAdamEMA:
         self.bucket_bytes = int(bucket_mb * 2 ** 20)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # dp: the bucketed all-reduce machinery is active (MADIFF_FORCE_DP=1 keeps it on in a 1-rank group: tests)
+        self.dp = self.world > 1 or (os.environ.get("MADIFF_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized())
+        self._graph_events = None        # bucket index -> graph-external event (while / after capturing a DP step)
+        self._graph_order: List[int] = []
         self.params: List[torch.nn.Parameter] = []
         self.names: List[str] = []
         self.flat_p = self.flat_g = self.flat_m = self.flat_v = self.flat_ema = None
@@ -144,7 +148,7 @@ class FlatAdamEMA:
             for i in b["members"]:
                 self._bucket_of[i] = b
         self._index = {id(p): i for i, p in enumerate(self.params)}
-        if self.world > 1:
+        if self.dp:
             if dev.type == "cuda":
                 self._comm_stream = torch.cuda.Stream(device=dev)
             for i, p in enumerate(self.params):
@@ -162,7 +166,7 @@ class FlatAdamEMA:
                     kind, taps, O, I, ipad = geom
                     sink.register_matrix(p, o, O, taps * ipad, kind, taps)
                     sink.shadow_state[id(p)] = (p._version, ops._EPOCH_EXT)
-            if self.world > 1:
+            if self.dp:
                 hooks = [self._make_hook(i) for i in range(len(self.params))]
                 sink.notify = lambda p: hooks[self._index[id(p)]](p)
             ops.SINK = sink
@@ -178,6 +182,19 @@ class FlatAdamEMA:
         return hook
 
     def _launch_bucket(self, b):
+        if self._graph_events is not None and torch.cuda.is_current_stream_capturing():
+            # Capturing a data-parallel step (GraphedTrainStep): no collective goes into the graph.  The bucket's
+            # completion becomes a graph-external event node; after each replay the communication stream waits on it and
+            # runs the all-reduce eagerly, overlapped with the rest of the replayed backward pass.
+            cur = torch.cuda.current_stream()
+            for st in ops.AUX_STREAMS.values():       # members may have been produced on a parallel branch
+                if st.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(st)
+            bi = self.buckets.index(b)
+            lib.call("madiff_event_record_external", self._graph_events[bi], cur.cuda_stream)
+            self._graph_order.append(bi)
+            b["work"] = "graph"
+            return
         g = self.flat_g[b["lo"]:b["hi"]]
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
@@ -206,13 +223,46 @@ class FlatAdamEMA:
                 b["pending"] = len(b["members"])
                 b["work"] = None
 
+    # -- data-parallel step replayed from a hipGraph (GraphedTrainStep) ---------------------------------------
+    def begin_graph_capture(self):
+        import ctypes
+        assert self.dp and self._comm_stream is not None and self.flat_g is not None
+        if self._graph_events is None:
+            self._graph_events = {}
+            for bi in range(len(self.buckets)):
+                h = ctypes.c_void_p()
+                lib.call("madiff_event_create", ctypes.byref(h))
+                self._graph_events[bi] = h.value
+        self._graph_order = []
+        self.set_sync(True)
+
+    def allreduce_after_replay(self):
+        """Called right after graph.replay(): start every bucket's all-reduce on the communication stream as soon as
+        its event node inside the running graph has fired; the caller's stream then waits for all of them."""
+        assert self._graph_order, "no bucket completion was recorded while capturing"
+        cs = self._comm_stream
+        works = []
+        for bi in self._graph_order:
+            b = self.buckets[bi]
+            lib.call("madiff_stream_wait_event", cs.cuda_stream, self._graph_events[bi])
+            with torch.cuda.stream(cs):
+                works.append(dist.all_reduce(self.flat_g[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        with torch.cuda.stream(cs):
+            for w in works:
+                w.wait()
+        torch.cuda.current_stream().wait_stream(cs)
+        for b in self.buckets:
+            b["work"] = "done"
+
     def _finish_allreduce(self):
-        if self.world <= 1:
+        if not self.dp:
             return
         if not self._hooks:            # first step: buffers were created after backward -> reduce everything now
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
             return
         for b in self.buckets:
+            if b["work"] == "done":    # reduced by allreduce_after_replay()
+                continue
             if b["work"] is None:      # a bucket whose hooks did not all fire (should not happen) -> reduce now
                 self._launch_bucket(b)
             b["work"].wait()
@@ -293,12 +343,16 @@ class GraphedTrainStep:
         (ma_temporal.py:346-351) and copied over,
       * {completed steps, EMA mode} for the Adam kernel's bias corrections (device int32[2]).
     The diffusion timestep t and the noise are drawn inside the graph by torch's graph-safe Philox generator, in the
-    reference's order.  Single-process only (world_size 1): the data-parallel path keeps the eager, overlapped step.
+    reference's order.  Data-parallel jobs (world_size > 1): the graph holds loss forward + backward only and every
+    gradient bucket's completion is a graph-EXTERNAL event node; after each replay the communication stream waits on
+    those events and all-reduces the buckets eagerly (no collective inside the graph), overlapped with the rest of the
+    replayed backward pass, then the fused Adam/EMA launch follows eagerly.
     Call after at least one eager train_step (buffers materialised, GEMM variants tuned)."""
 
     def __init__(self, diffusion, opt: FlatAdamEMA, example_batch: dict, draws: Optional[dict] = None):
         """draws = {"t", "noise", "dropout_mask"} fixes the random draws of every replay (parity tests)."""
-        assert opt.world == 1 and opt.flat_p is not None and opt.use_hip
+        assert opt.flat_p is not None and opt.use_hip
+        self.dp = opt.dp
         self.draws = None if draws is None else {k: v.clone() for k, v in draws.items()}
         self.diffusion, self.opt = diffusion, opt
         clone = lambda v: {k: clone(u) for k, u in v.items()} if isinstance(v, dict) else v.clone()  # noqa: E731
@@ -324,22 +378,33 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        if self.dp:
+            opt.begin_graph_capture()
         with torch.cuda.graph(self.graph):
             self.loss, self.infos = self._body(captured=True)
+        if self.dp:
+            assert sorted(opt._graph_order) == list(range(len(opt.buckets))), "a gradient bucket never completed"
         # the step counter lives on the device from here on: the captured Adam launch reads it and a captured
         # one-thread kernel increments it after every replay
         self.state.copy_(torch.tensor([opt.step_count, 0], dtype=torch.int32))
 
     def _body(self, captured: bool = False):
         extra = {} if self.draws is None else {"t": self.draws["t"], "noise": self.draws["noise"]}
+        if not captured:
+            self.opt.set_sync(True)
         loss, infos = self.diffusion.loss(**self.batch, dropout_mask=self.mask, **extra)
         loss.backward()
-        if captured:
+        if captured and self.dp:
+            # data parallel: the graph ends with backward; all-reduce and Adam are issued after each replay
+            for st in ops.AUX_STREAMS.values():
+                torch.cuda.current_stream().wait_stream(st)
+        elif captured:
             self.opt.step(device_state=self.state)      # launches only; host-side counters advance in step()
             self.opt.step_count -= 1
+            self.opt.zero_grad()
         else:
             self.opt.step(0)
-        self.opt.zero_grad()
+            self.opt.zero_grad()
         return loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in infos.items()}
 
     def _copy_in(self, dst, src):
@@ -362,6 +427,12 @@ class GraphedTrainStep:
             ev.record()
         if self.opt.ema_module is None:
             do_ema = 0
+        if self.dp:
+            self.graph.replay()
+            self.opt.allreduce_after_replay()
+            self.opt.step(do_ema)                  # eager fused Adam/EMA (host-side step counter), clears the gradient
+            self.opt.zero_grad()
+            return self.loss, self.infos
         self.state[1:].fill_(int(do_ema))      # the value travels as a kernel argument: no host buffer to race on
         self.graph.replay()
         self.opt.step_count += 1
