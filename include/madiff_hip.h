@@ -31,6 +31,16 @@ typedef void* madiff_stream_t; /* hipStream_t */
 int madiff_version(void);
 const char* madiff_arch(void);
 
+/* Conv1dBlock forward in one launch (bf16 build; helpers.py:50-74 + temporal.py:197-200): Conv1d(k=5, pad=2) + bias ->
+ * GroupNorm(G) -> Mish -> (+ rowbias[n, c] (mode 1) | + res[(n,t), c] (mode 2)).  The all-taps convolution kernel's output
+ * tile holds whole sequences x whole groups, so the normalisation is its epilogue.  Y = pre-norm output kept for
+ * backward (NULL under no_grad, then mean/rstd may be NULL too).  variant 0/1 = 192/96-row tile.  Returns 1 when the
+ * layer is not covered (use madiff_gemm_fwd + madiff_gn_mish_fwd). */
+int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, int ldx2, int Csplit, int M, int Cin, int T,
+                            const void* W, int ldw, int Nout, const float* bias, void* Y, int ldy, void* out, int ldo,
+                            const float* gamma, const float* beta, float* mean, float* rstd, int G, float eps, int mode,
+                            const float* rowbias, int ldrb, const void* res, int ldr, int variant, madiff_stream_t stream);
+
 /* Graph-external events (no counterpart in the reference, which has neither graphs nor data parallelism): a record
  * issued on a capturing stream becomes an event-record node of the hipGraph, so a stream outside the graph (the RCCL
  * communication stream of madiff_amd/trainer.py) can wait for "gradient bucket b is complete" inside a replayed

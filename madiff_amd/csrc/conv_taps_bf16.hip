@@ -43,8 +43,25 @@ __device__ __forceinline__ void ct_dma16(const void* gbase, unsigned voff, unsig
 }
 
 // shift(tap) = shift0 + tap * shift_step: forward (tr = 0) -pad + tap, data gradient (tr = 1) pad - tap
-template <int WM, bool WT, int D>
-__global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams p, int rows_used, int shift0, int shift_step) {
+// Fused epilogue of the forward kernel: GroupNorm(G) + Mish (+ per-sequence row bias | + residual) of Conv1dBlock
+// (helpers.py:63-71, temporal.py:197-200).  The output tile holds whole sequences x whole groups, so the statistics never
+// leave the workgroup.
+struct GnEpi {
+  const float* gamma; const float* beta;      // [C]
+  float* mean; float* rstd;                   // [n_seq * G] saved for backward, or null
+  bf16_t* out; int ldo;                       // normalised + activated output
+  int write_y;                                // 1: also store the pre-norm conv output to p.C (needed by backward)
+  int mode;                                   // 0 plain, 1 + rowbias[n, c], 2 + res[(n,t), c]
+  const float* rowbias; int ldrb;
+  const bf16_t* res; int ldr;
+  int G, gv_log2;                             // groups; log2(16-byte... 8-channel vectors per group)
+  float eps;
+};
+
+template <int WM, bool WT, int D, bool GN>
+__global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams p, int rows_used, int shift0, int shift_step,
+                                                                  GnEpi ge) {
+  static_assert(!(GN && WT), "the GroupNorm epilogue belongs to the forward kernel");
   constexpr int TAPS = 5;
   static_assert(D == 3 || D == 4, "W ring depth");
   constexpr int BM = 48 * WM, NW = 2 * WM, NT = NW * 64;
@@ -231,6 +248,104 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
     }
   }
 
+  if constexpr (GN) {
+    // ---- fused GroupNorm + Mish epilogue.  (1) accumulators + conv bias -> fp32 LDS image of the whole tile;
+    // (2) a wave takes whole sequences: lane = (row r0 = lane / 16, 8-channel vector cv = lane % 16), iteration i covers
+    // row r0 + 4 i; group statistics are butterfly sums over the lane bits inside a group (as gn_mish_fwd_rb_kernel);
+    // (3) y (pre-norm, for backward) and the activated output leave as 16-byte vectors.
+    constexpr int LDG = 132;
+    constexpr int VMAX = 8;                  // T <= 32
+    static_assert(BM * LDG * 4 <= 2 * A_BYTES + D * W_BYTES, "tile image must fit the operand LDS");
+    float* tile = (float*)smem;
+    __syncthreads();                         // every wave is done with the operand tiles; no DMA is outstanding
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int col = wn * 64 + j * 16 + fr;
+      const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) tile[(wm * 48 + i * 16 + fq * 4 + r) * LDG + col] = acc[i][j][r] + bv;
+    }
+    __syncthreads();
+    const int cv = lane & 15, r0 = lane >> 4, c0 = n0 + cv * 8;
+    const int Cg = p.Nout / ge.G;
+    const float inv_e = 1.f / (float)(T * Cg);
+    const int spt = rows_used / T, n_seq = p.M / T;
+    float gmv[8], btv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { gmv[e] = ge.gamma[c0 + e]; btv[e] = ge.beta[c0 + e]; }
+    bf16_t* Y = (bf16_t*)p.C;
+    for (int sq = wave; sq < spt; sq += NW) {
+      const int n = blockIdx.x * spt + sq;
+      if (n >= n_seq) break;
+      const size_t rbase = (size_t)n * T;
+      float v[VMAX][8];
+      bf16x8 rs[VMAX];
+      float rb[8];
+#pragma unroll
+      for (int i = 0; i < VMAX; i++) {
+        const int r = r0 + 4 * i;
+        if (r < T) {
+          if (ge.mode == 2) rs[i] = *(const bf16x8*)(ge.res + (rbase + r) * ge.ldr + c0);
+          const f32x4 a = *(const f32x4*)&tile[(sq * T + r) * LDG + cv * 8];
+          const f32x4 b = *(const f32x4*)&tile[(sq * T + r) * LDG + cv * 8 + 4];
+          v[i][0] = a[0]; v[i][1] = a[1]; v[i][2] = a[2]; v[i][3] = a[3];
+          v[i][4] = b[0]; v[i][5] = b[1]; v[i][6] = b[2]; v[i][7] = b[3];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) rb[e] = ge.mode == 1 ? ge.rowbias[(size_t)n * ge.ldrb + c0 + e] : 0.f;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < VMAX; i++)
+        if (r0 + 4 * i < T) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) sum += v[i][e];
+          if (ge.write_y) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (bf16_t)v[i][e];
+            *(bf16x8*)(Y + (rbase + r0 + 4 * i) * p.ldc + c0) = o;
+          }
+        }
+      // lanes of one group differ in bits [0, gv_log2) (vector inside the group) and bits 4, 5 (row)
+      for (int b = 0; b < ge.gv_log2; b++) sum += __shfl_xor(sum, 1 << b, 64);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * inv_e;
+      float sqs = 0.f;
+#pragma unroll
+      for (int i = 0; i < VMAX; i++)
+        if (r0 + 4 * i < T) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) { const float d = v[i][e] - mean; sqs += d * d; }
+        }
+      for (int b = 0; b < ge.gv_log2; b++) sqs += __shfl_xor(sqs, 1 << b, 64);
+      sqs += __shfl_xor(sqs, 16, 64);
+      sqs += __shfl_xor(sqs, 32, 64);
+      const float rstd = rsqrtf(sqs * inv_e + ge.eps);
+      if (ge.mean && r0 == 0 && (cv & ((1 << ge.gv_log2) - 1)) == 0) {
+        const int g = c0 / Cg;
+        ge.mean[(size_t)n * ge.G + g] = mean;
+        ge.rstd[(size_t)n * ge.G + g] = rstd;
+      }
+      float sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) { sc[e] = rstd * gmv[e]; sh[e] = btv[e] - mean * sc[e]; }
+#pragma unroll
+      for (int i = 0; i < VMAX; i++)
+        if (r0 + 4 * i < T) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; e++)
+            o[e] = (bf16_t)(mish_f(v[i][e] * sc[e] + sh[e]) + (ge.mode == 2 ? (float)rs[i][e] : rb[e]));
+          *(bf16x8*)(ge.out + (rbase + r0 + 4 * i) * ge.ldo + c0) = o;
+        }
+    }
+    return;
+  }
+
   // ---- epilogue (vector path only; the launcher checks the alignment preconditions)
   bf16_t* C = (bf16_t*)p.C;
   constexpr int WN = 64, LDT = WN + 4, VPR = WN / 8, RPP = 64 / VPR;
@@ -315,13 +430,56 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_bf1
   const int n_seq = p.M / T;
   const int shift0 = p.rm.tr ? p.rm.pad : -p.rm.pad, shift_step = p.rm.tr ? -1 : 1;
   dim3 grid((n_seq + spt - 1) / spt, (p.Npad + 127) / 128);
-#define CT_LAUNCH(WM_, WT_, D_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, WT_, D_>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, shift0, shift_step)
+  GnEpi ge = {};
+#define CT_LAUNCH(WM_, WT_, D_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, WT_, D_, false>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, shift0, shift_step, ge)
   if (variant == 0) {          // 192 rows: one 8-wave workgroup per CU, 4-deep W ring
     if (p.wt) CT_LAUNCH(4, true, 4); else CT_LAUNCH(4, false, 4);
   } else {                     // 96 rows: two 4-wave workgroups per CU (75 KB of LDS each), 3-deep W ring
     if (p.wt) CT_LAUNCH(2, true, 3); else CT_LAUNCH(2, false, 3);
   }
 #undef CT_LAUNCH
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Conv1dBlock forward in one launch: k5 "same" convolution + bias + GroupNorm(G) + Mish (+ rowbias | + residual).
+// p: the convolution (p.C / p.ldc = pre-norm output y, written only when write_y).  Returns 1 when the layer is not
+// covered (the caller then runs the convolution and madiff_gn_mish_fwd separately).
+extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_bf16(
+    const void* params, int variant, void* out, int ldo, const float* gamma, const float* beta, float* mean, float* rstd, int G,
+    float eps, int mode, const float* rowbias, int ldrb, const void* res, int ldr, int write_y, hipStream_t stream) {
+  GemmFwdParams p = *(const GemmFwdParams*)params;
+  const int BM = variant == 0 ? 192 : 96;
+  const int T = p.rm.T_out;
+  if (p.wt || p.taps != 5 || p.rm.stride != 1 || p.rm.tr != 0 || p.rm.pad != 2 || p.rm.T_in != T || T > 32 || p.permA > 0 ||
+      p.ksplit > 1 || p.Cin % 64 || p.Csplit % 64 || p.M % T || p.act != 0 || p.rowbias)
+    return 1;
+  if (G <= 0 || p.Nout % 128 || p.Npad != p.Nout || p.Nout % G) return 1;
+  const int Cg = p.Nout / G;
+  if (Cg % 8 || 128 % Cg) return 1;
+  int gl = 0;
+  while ((8 << gl) < Cg) gl++;
+  if ((8 << gl) != Cg) return 1;
+  if (mode < 0 || mode > 2 || (mode == 1 && (!rowbias || ldrb < p.Nout)) || (mode == 2 && (!res || ldr < p.Nout))) return -1;
+  if (!out || !gamma || !beta || ldo < p.Nout || (write_y && (!p.C || p.ldc < p.Nout))) return -1;
+  if (((size_t)out % 16) || (ldo % 8) || (write_y && (((size_t)p.C % 16) || p.ldc % 8)) ||
+      (mode == 2 && (((size_t)res % 16) || ldr % 8)))
+    return 1;
+  {
+    const size_t ldmax = (size_t)(p.ldx > p.ldx2 ? p.ldx : p.ldx2);
+    if ((size_t)p.M * ldmax * 2 >= (1ull << 31) || (size_t)p.Nout * p.ldw * 2 >= (1ull << 31)) return 1;
+  }
+  GnEpi ge;
+  ge.gamma = gamma; ge.beta = beta; ge.mean = mean; ge.rstd = rstd; ge.out = (bf16_t*)out; ge.ldo = ldo;
+  ge.write_y = write_y ? 1 : 0; ge.mode = mode; ge.rowbias = rowbias; ge.ldrb = ldrb; ge.res = (const bf16_t*)res; ge.ldr = ldr;
+  ge.G = G; ge.gv_log2 = gl; ge.eps = eps;
+  const int spt = BM / T, rows_used = spt * T;
+  const int n_seq = p.M / T;
+  dim3 grid((n_seq + spt - 1) / spt, p.Nout / 128);
+  if (variant == 0)
+    hipLaunchKernelGGL((conv_taps_bf16_kernel<4, false, 4, true>), grid, dim3(512), 0, stream, p, rows_used, -2, 1, ge);
+  else
+    hipLaunchKernelGGL((conv_taps_bf16_kernel<2, false, 3, true>), grid, dim3(256), 0, stream, p, rows_used, -2, 1, ge);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

@@ -343,6 +343,10 @@ extern "C" int madiff_launch_gemm_fwd_bf16(const void* params, int out_f32, int 
 extern "C" int madiff_launch_gemm_wgrad_bf16(const void* params, int tile, int gx, int gy, int gz, hipStream_t stream);
 extern "C" int madiff_launch_gemm_wgrad_taps_bf16(const void* params, int variant, int nq, int gx, int gy, int gz, hipStream_t stream);
 extern "C" int madiff_launch_conv_taps_bf16(const void* params, int out_f32, int variant, hipStream_t stream);
+extern "C" int madiff_launch_conv_taps_gn_bf16(const void* params, int variant, void* out, int ldo, const float* gamma,
+                                               const float* beta, float* mean, float* rstd, int G, float eps, int mode,
+                                               const float* rowbias, int ldrb, const void* res, int ldr, int write_y,
+                                               hipStream_t stream);
 
 // MADIFF_GEMM_IMPL=0 forces the generic register-staged kernel for bf16 too (A/B timing, debugging)
 static int use_dma_kernel() {
@@ -429,6 +433,32 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   }
   MADIFF_CHECK_LAUNCH();
   return 0;
+}
+
+// Conv1dBlock forward (helpers.py:50-74) in ONE launch, bf16 build: Conv1d(k=5, padding=2) + bias -> GroupNorm(G) -> Mish,
+// then + rowbias[n, c] (mode 1: the time-embedding projection, temporal.py:197) or + res[(n,t), c] (mode 2: the
+// residual branch, temporal.py:200).  Y (pre-norm conv output, bf16 [M, ldy]) is what backward needs; pass Y = NULL
+// under no_grad to skip that write.  mean / rstd [M/T * G] may be NULL together with Y.  variant: 0 = 192-row tile,
+// 1 = 96-row tile.  Returns 1 when the layer is not covered (caller: madiff_gemm_fwd + madiff_gn_mish_fwd).
+extern "C" int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, int ldx2, int Csplit, int M, int Cin, int T,
+                                       const void* W, int ldw, int Nout, const float* bias, void* Y, int ldy, void* out,
+                                       int ldo, const float* gamma, const float* beta, float* mean, float* rstd, int G,
+                                       float eps, int mode, const float* rowbias, int ldrb, const void* res, int ldr,
+                                       int variant, hipStream_t stream) {
+  if (M <= 0 || Nout <= 0) return 0;
+  if (!use_dma_kernel()) return 1;
+  if (T <= 0 || Cin <= 0 || M % T || ldw < 5 * Cin || (ldw * 2) % 16 || (ldx * 2) % 16 || variant < 0 || variant > 1) return -1;
+  if (X2 == nullptr) Csplit = Cin;
+  if (Csplit > Cin || ldx < Csplit || (X2 && (ldx2 < Cin - Csplit || (ldx2 * 2) % 16))) return -1;
+  GemmFwdParams p;
+  p.X = X; p.ldx = ldx; p.X2 = X2; p.ldx2 = ldx2; p.Csplit = Csplit;
+  p.M = M; p.Cin = Cin; p.taps = 5;
+  p.rm = RowMap{T, T, 1, 2, 0};
+  p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Nout; p.bias = bias; p.rowbias = nullptr; p.ldrb = 0;
+  p.C = Y; p.ldc = ldy; p.act = 0; p.permT = 0; p.permA = 0;
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1;
+  return madiff_launch_conv_taps_gn_bf16(&p, variant, out, ldo, gamma, beta, mean, rstd, G, eps, mode, rowbias, ldrb, res,
+                                         ldr, Y != nullptr, stream);
 }
 
 // Data gradient of a layer straight from its FORWARD bf16 weight matrix W [Kred = Opad rows, ldw = taps*wtap]:

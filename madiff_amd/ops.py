@@ -840,6 +840,65 @@ def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None):
     return dy, outs[0], outs[1], outs[2], drb, dout
 
 
+FUSE_CONV_GN = os.environ.get("MADIFF_FUSE_CONV_GN", "1") != "0"
+
+
+def _conv_block_fused(x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w, b, gamma, beta, need_y: bool):
+    """Conv1dBlock forward as ONE launch (madiff_conv_gn_mish_fwd: the all-taps k5 kernel with the GroupNorm + Mish
+    epilogue).  Returns (out, y | None, stats | None, g, geom) or None when the layer is not covered."""
+    if not FUSE_CONV_GN or _PRECISION != "bf16" or spec is not CONV5 or not x.is_cuda:
+        return None
+    O, I, so, si, st = _strides(spec.kind, w)
+    c1 = x.shape[1]
+    cin = c1 + (x2.shape[1] if x2 is not None else 0)
+    if O % 128 or O % G or cin % 64 or c1 % 64 or t_in > 32 or not (cin == pad32(I) or (x2 is not None and cin == I)):
+        return None
+    Cg = O // G
+    if Cg % 8 or 128 % Cg or (Cg // 8) & (Cg // 8 - 1):
+        return None
+    _chk_cl(x)
+    if x2 is not None:
+        _chk_cl(x2)
+    M = x.shape[0]
+    n_seq = M // t_in
+    W = _packed([w], spec, False)
+    out = torch.empty(M, O, dtype=act_dtype(), device=x.device)
+    y = torch.empty(M, O, dtype=act_dtype(), device=x.device) if need_y else None
+    stats = torch.empty(2, n_seq * G, dtype=torch.float32, device=x.device) if need_y else None
+    mode = 1 if rowbias is not None else (2 if res is not None else 0)
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.stride(1) == 1
+    if res is not None:
+        _chk_cl(res)
+
+    def launch(variant):
+        return lib.call_rc("madiff_conv_gn_mish_fwd", x.data_ptr(), x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0),
+                           c1, M, cin, t_in, W.data_ptr(), W.stride(0), O, _p(b), _p(y), O, out.data_ptr(), O,
+                           gamma.data_ptr(), beta.data_ptr(), None if stats is None else stats[0].data_ptr(),
+                           None if stats is None else stats[1].data_ptr(), G, 1e-5, mode, _p(rowbias),
+                           0 if rowbias is None else rowbias.stride(0), _p(res), 0 if res is None else res.stride(0), variant,
+                           _stream())
+
+    sig = ("convgn", M, cin, O, t_in, G, mode, need_y, x2 is not None)
+    variant = _tuned_tile(sig, (0, 1), launch)
+    if variant < 0:          # not tuned (graph capture of an unseen shape / tuning disabled): fill the chip
+        variant = 0 if (-(-n_seq // (192 // t_in))) * (O // 128) >= 200 else 1
+    g = _Geom()
+    g.flops = 2.0 * M * O * I * spec.taps
+    rc = [0]
+
+    def run():
+        rc[0] = launch(variant)
+        return "conv_taps_bf16_kernel"
+
+    _timed("conv_taps_bf16_kernel", g.flops, run)
+    if rc[0]:
+        return None
+    g.spec, g.t_in, g.t_out, g.act, g.perm = spec, t_in, t_in, 0, None
+    g.dims, g.osum, g.cin, g.c1, g.n_seq, g.I = [(O, I, so, si, st)], O, cin, c1, n_seq, I
+    return out, y, stats, g, (n_seq, t_in, O, O, G, mode)
+
+
 class ConvBlock(torch.autograd.Function):
     """Conv1dBlock as ONE autograd node: implicit-GEMM conv -> GroupNorm -> Mish (+ rowbias | + residual).
     Backward: fused GN/Mish backward (which also yields the conv-bias gradient), then data + weight gradient GEMMs.
@@ -848,8 +907,12 @@ class ConvBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w, b, gamma, beta):
-        y, g = _conv_forward(x, x2, None, spec, t_in, 0, None, [w], [b])
-        out, stats, geom = _gn_forward(y, gamma, beta, rowbias, res, g.n_seq, g.t_out, g.osum, G)
+        fused = _conv_block_fused(x, x2, rowbias, res, spec, t_in, G, w, b, gamma, beta, any(ctx.needs_input_grad))
+        if fused is not None:
+            out, y, stats, g, geom = fused
+        else:
+            y, g = _conv_forward(x, x2, None, spec, t_in, 0, None, [w], [b])
+            out, stats, geom = _gn_forward(y, gamma, beta, rowbias, res, g.n_seq, g.t_out, g.osum, G)
         ctx.save_for_backward(x, x2, y, stats, w, b, gamma, beta)
         ctx.g, ctx.geom = g, geom
         return out

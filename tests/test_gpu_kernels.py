@@ -461,3 +461,54 @@ def test_graphed_train_step_matches_eager_steps(dp):
         os.environ.pop("MADIFF_FORCE_DP", None)
         if dp and dist.is_initialized():
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["t6_c128", "t12_c512_x2", "t24_c128", "t7_c256_ragged"])
+@pytest.mark.parametrize("mode", ["plain", "temb", "res"])
+def test_conv_block_fused_matches_unfused(case, mode):
+    """madiff_conv_gn_mish_fwd (all-taps k5 convolution with the GroupNorm + Mish epilogue, one launch) against the
+    two-launch path (madiff_gemm_fwd + madiff_gn_mish_fwd) and against torch fp32, with and without the pre-norm output."""
+    from madiff_amd import modules as M, ops
+    ops.set_precision("bf16")
+    dev = _dev()
+    N, T, C1, C2, Co = {"t6_c128": (37, 6, 128, 0, 128), "t12_c512_x2": (19, 12, 128, 128, 512),
+                        "t24_c128": (9, 24, 64, 0, 128), "t7_c256_ragged": (41, 7, 192, 0, 256)}[case]
+    G = 8
+    Cin = C1 + C2
+    x = _q(_rand(N, Cin, T, seed=1), "bf16").to(dev)
+    w = _q(_rand(Co, Cin, 5, seed=2, scale=1 / math.sqrt(Cin * 5)), "bf16").to(dev)
+    b = _rand(Co, seed=3).to(dev)
+    gamma = (1 + 0.3 * _rand(Co, seed=4)).to(dev)
+    beta = (0.2 * _rand(Co, seed=5)).to(dev)
+    rowbias = _rand(N, Co, seed=6).to(dev) if mode == "temb" else None
+    res = M.to_cl(_q(_rand(N, Co, T, seed=7), "bf16").to(dev)) if mode == "res" else None
+    ref = F.mish(F.group_norm(F.conv1d(x, w, b, padding=2), G, gamma, beta, eps=1e-5))
+    if rowbias is not None:
+        ref = ref + rowbias[:, :, None]
+    if res is not None:
+        ref = ref + M.from_cl(res, N, T, Co)
+    xcl = M.to_cl(x)
+    xa, xb = (xcl[:, :C1].contiguous(), xcl[:, C1:].contiguous()) if C2 else (xcl, None)
+    old = ops.FUSE_CONV_GN
+    try:
+        outs = {}
+        for fuse in (False, True):
+            ops.FUSE_CONV_GN = fuse
+            for need_y in (True, False):
+                r = ops._conv_block_fused(xa, xb, rowbias, res, ops.CONV5, T, G, w, b, gamma, beta, need_y) if fuse else None
+                if fuse:
+                    assert r is not None, "layer should be covered by the fused kernel"
+                    out, y, stats = r[0], r[1], r[2]
+                    assert (y is None) == (not need_y)
+                else:
+                    y, g = ops._conv_forward(xa, xb, None, ops.CONV5, T, 0, None, [w], [b])
+                    out, stats, _ = ops._gn_forward(y, gamma, beta, rowbias, res, N, T, Co, G)
+                outs[(fuse, need_y)] = (out, y, stats)
+                assert rel_err(M.from_cl(out, N, T, Co).cpu(), ref.cpu()) < TOL["bf16"], (fuse, need_y)
+        o0, y0, s0 = outs[(False, True)]
+        o1, y1, s1 = outs[(True, True)]
+        assert rel_err(y1.float().cpu(), y0.float().cpu()) < 1e-2
+        assert rel_err(s1.cpu(), s0.cpu()) < 1e-2                 # statistics: fp32 accumulators vs the bf16-rounded y
+        assert torch.equal(outs[(True, False)][0], o1)             # dropping the y store changes nothing else
+    finally:
+        ops.FUSE_CONV_GN = old
