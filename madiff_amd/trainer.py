@@ -46,6 +46,7 @@ class FlatAdamEMA:
         self.buckets: List[dict] = []
         self._hooks = []
         self._sync_this_backward = True
+        self._notified = set()
         self._comm_stream = None
         self.use_hip = use_hip_kernel
         self.grad_scale = 1.0
@@ -175,6 +176,11 @@ class FlatAdamEMA:
         def hook(_p):
             if not self._sync_this_backward:
                 return
+            # a parameter can be announced twice in one backward: by the kernel that accumulated its gradient straight
+            # into the flat buffer (GradSink.done) and again by autograd's post-accumulate hook; count it once
+            if i in self._notified:
+                return
+            self._notified.add(i)
             b = self._bucket_of[i]
             b["pending"] -= 1
             if b["pending"] == 0:
@@ -218,6 +224,7 @@ class FlatAdamEMA:
     def set_sync(self, flag: bool):
         """Only the last micro-batch of an accumulation group triggers the all-reduce (no_sync equivalent)."""
         self._sync_this_backward = flag
+        self._notified = set()
         if flag:
             for b in self.buckets:
                 b["pending"] = len(b["members"])
