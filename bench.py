@@ -130,7 +130,8 @@ def main():
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="single-GPU: issue the step eagerly instead of replaying a hipGraph")
-    ap.add_argument("--sample-batch", type=int, default=256)
+    ap.add_argument("--sample-batch", type=int, default=1024,
+                    help="episodes sampled per GPU (BASELINE.json configs[4]: 8192 episodes over 8 GPUs = 1024 per GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,8 +218,10 @@ def main():
     sample = None
     if not args.no_sample:
         sb = args.sample_batch
-        cond = {"x": batch["cond"]["x"][:sb].contiguous(), "masks": batch["cond"]["masks"][:sb].contiguous()}
-        ret = batch["returns"][:sb].contiguous()
+        sbatch = synthetic_batch(sb, device, seed=1000 + rank)
+        cond = {"x": sbatch["cond"]["x"].contiguous(), "masks": sbatch["cond"]["masks"].contiguous()}
+        ret = sbatch["returns"].contiguous()
+        assert cond["x"].shape[0] == sb
         ema.conditional_sample(cond, returns=ret, verbose=False)          # warm-up (allocator, pack cache)
         barrier()
         s0 = time.perf_counter()
