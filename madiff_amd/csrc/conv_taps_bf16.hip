@@ -58,12 +58,14 @@ struct GnEpi {
   float eps;
 };
 
+// D = 3 / 4: one barrier per (chunk, tap) step.  D = 5: one barrier per TWO steps (the ring then holds the three stages a
+// double-step reads or prefetches from plus the two in flight; needs an even number of channel chunks).
 template <int WM, bool WT, int D, bool GN>
 __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams p, int rows_used, int shift0, int shift_step,
                                                                   GnEpi ge) {
   static_assert(!(GN && WT), "the GroupNorm epilogue belongs to the forward kernel");
   constexpr int TAPS = 5;
-  static_assert(D == 3 || D == 4, "W ring depth");
+  static_assert(D == 3 || D == 4 || D == 5, "W ring depth");
   constexpr int BM = 48 * WM, NW = 2 * WM, NT = NW * 64;
   constexpr int MI = 3, NJ = 4;
   constexpr int A_TILE = BM * 128, A_BYTES = A_TILE + 1024, W_BYTES = 128 * 128;
@@ -193,6 +195,60 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   const int nc = p.Cin >> 6;
   bf16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
   __syncthreads();                         // zero rows written before any fragment read
+  if constexpr (D == 5) {
+    // ---- one barrier per two steps.  Flat step s = 5 c + tap, W(s) lives in ring slot s % 5, A(c) in buffer c & 1; the
+    // loop body covers two chunks = ten steps, so every LDS offset below is a compile-time constant.  At the barrier
+    // before even step s: W(s), W(s+1), W(s+2) and the A chunks they (or the kh = 0 prefetch of step s+2) touch are
+    // complete (each wave drained its own DMA first: everything outstanding was issued one double-step earlier);
+    // then W(s+3), W(s+4) are issued into the slots of W(s-2), W(s-1), A(c1) after the barrier of step 0 and the next
+    // pair's A(c0) after the barrier of step 6 (its buffer was last read in step 4).
+    const int nsteps = nc * TAPS;
+    issueA(0);
+    issueW(0, 0, 0);
+    issueW(1, 0, 1);
+    issueW(2, 0, 2);
+    ct_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(a0, b0, smem, Wbase, offA[0], 0);
+    for (int c0 = 0; c0 < nc; c0 += 2) {
+      const int sbase = c0 * TAPS;
+#pragma unroll
+      for (int f = 0; f < 2 * TAPS; f++) {
+        const int cc = f / TAPS, tap = f % TAPS;            // chunk c0 + cc, compile-time tap
+        const int s = sbase + f;
+        const bool last = s + 1 == nsteps;
+        if ((f & 1) == 0) {
+          if (f > 0 || c0 > 0) {                            // (the prologue did this for the very first step)
+            ct_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+          }
+          if (f == 0 && c0 + 1 < nc) issueA(c0 + 1);
+          if (f == 6 && c0 + 2 < nc) issueA(c0 + 2);
+#pragma unroll
+          for (int q = 3; q <= 4; q++) {
+            const int f2 = f + q;                           // flat index inside / beyond this pair
+            const int c2 = c0 + f2 / TAPS, t2 = f2 % TAPS;
+            if (c2 < nc) issueW(t2, c2, f2 % 5);
+          }
+        }
+        const unsigned char* As = smem + cc * A_BYTES;
+        const unsigned char* Ws = Wbase + (f % 5) * W_BYTES;
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(a1, b1, As, Ws, offA[tap], 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!last) {
+          const int fn = f + 1;
+          const unsigned char* An = smem + ((fn / TAPS) & 1) * A_BYTES;
+          load_frags(a0, b0, An, Wbase + (fn % 5) * W_BYTES, offA[fn % TAPS], 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
   issueA(0);
 #pragma unroll
   for (int d = 0; d < D - 1; d++) issueW(d, 0, d);
@@ -246,6 +302,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       __builtin_amdgcn_sched_barrier(0);
       slot = nslot;
     }
+  }
   }
 
   if constexpr (GN) {
@@ -410,8 +467,9 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
 extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_bf16(const void* params, int out_f32, int variant,
                                                                                   hipStream_t stream) {
   GemmFwdParams p = *(const GemmFwdParams*)params;
-  const int BM = variant == 0 ? 192 : 96;
+  const int BM = variant == 1 ? 96 : 192;
   const int T = p.rm.T_out;
+  if (variant == 2 && p.Cin % 128) return 1;      // the two-steps-per-barrier loop covers chunk pairs
   if (out_f32 || p.taps != 5 || p.rm.stride != 1 || p.rm.T_in != T || T > BM || p.permA > 0 || p.ksplit > 1 ||
       p.Cin % 64 || p.Csplit % 64 || p.M % T)
     return 1;
@@ -432,7 +490,9 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_bf1
   dim3 grid((n_seq + spt - 1) / spt, (p.Npad + 127) / 128);
   GnEpi ge = {};
 #define CT_LAUNCH(WM_, WT_, D_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, WT_, D_, false>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, shift0, shift_step, ge)
-  if (variant == 0) {          // 192 rows: one 8-wave workgroup per CU, 4-deep W ring
+  if (variant == 2) {          // 192 rows, 5-deep W ring, one barrier per two (chunk, tap) steps
+    if (p.wt) CT_LAUNCH(4, true, 5); else CT_LAUNCH(4, false, 5);
+  } else if (variant == 0) {   // 192 rows: one 8-wave workgroup per CU, 4-deep W ring
     if (p.wt) CT_LAUNCH(4, true, 4); else CT_LAUNCH(4, false, 4);
   } else {                     // 96 rows: two 4-wave workgroups per CU (75 KB of LDS each), 3-deep W ring
     if (p.wt) CT_LAUNCH(2, true, 3); else CT_LAUNCH(2, false, 3);
@@ -449,8 +509,9 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_
     const void* params, int variant, void* out, int ldo, const float* gamma, const float* beta, float* mean, float* rstd, int G,
     float eps, int mode, const float* rowbias, int ldrb, const void* res, int ldr, int write_y, hipStream_t stream) {
   GemmFwdParams p = *(const GemmFwdParams*)params;
-  const int BM = variant == 0 ? 192 : 96;
+  const int BM = variant == 1 ? 96 : 192;
   const int T = p.rm.T_out;
+  if (variant == 2 && p.Cin % 128) return 1;
   if (p.wt || p.taps != 5 || p.rm.stride != 1 || p.rm.tr != 0 || p.rm.pad != 2 || p.rm.T_in != T || T > 32 || p.permA > 0 ||
       p.ksplit > 1 || p.Cin % 64 || p.Csplit % 64 || p.M % T || p.act != 0 || p.rowbias)
     return 1;
@@ -476,7 +537,9 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_
   const int spt = BM / T, rows_used = spt * T;
   const int n_seq = p.M / T;
   dim3 grid((n_seq + spt - 1) / spt, p.Nout / 128);
-  if (variant == 0)
+  if (variant == 2)
+    hipLaunchKernelGGL((conv_taps_bf16_kernel<4, false, 5, true>), grid, dim3(512), 0, stream, p, rows_used, -2, 1, ge);
+  else if (variant == 0)
     hipLaunchKernelGGL((conv_taps_bf16_kernel<4, false, 4, true>), grid, dim3(512), 0, stream, p, rows_used, -2, 1, ge);
   else
     hipLaunchKernelGGL((conv_taps_bf16_kernel<2, false, 3, true>), grid, dim3(256), 0, stream, p, rows_used, -2, 1, ge);

@@ -365,11 +365,11 @@ static int check_rowmap(int T_out, int T_in, int stride, int pad, int tr) {
 // tiles re-read more operand bytes per FLOP (eff).
 // ids 14, 15: the all-taps k5 kernel (conv_taps_bf16.hip), 192- and 96-row tiles; they cover stride-1 "same" k5 layers
 // only and the entry points return 1 ("not covered") for any other layer
-static const int kNumTiles = 16;
-static const int kFirstTapsTile = 14;
-static const int kTileBM[kNumTiles] = {128, 96, 64, 128, 96, 64, 128, 96, 64, 128, 96, 64, 64, 64, 192, 96};
-static const int kTileBN[kNumTiles] = {128, 128, 128, 64, 64, 64, 128, 128, 128, 64, 64, 64, 128, 64, 128, 128};
-static const int kTileD[kNumTiles] = {2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 3, 3};
+static const int kNumTiles = 17;
+static const int kFirstTapsTile = 14;     // 14: 192 rows, 15: 96 rows, 16: 192 rows with one barrier per two steps
+static const int kTileBM[kNumTiles] = {128, 96, 64, 128, 96, 64, 128, 96, 64, 128, 96, 64, 64, 64, 192, 96, 192};
+static const int kTileBN[kNumTiles] = {128, 128, 128, 64, 64, 64, 128, 128, 128, 64, 64, 64, 128, 64, 128, 128, 128};
+static const int kTileD[kNumTiles] = {2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 3, 5};
 static int pick_tile(int M, int Npad, int wt) {
   static const double eff[6] = {1.0, 0.93, 0.85, 0.85, 0.78, 0.70};
   int best = 0;
@@ -447,7 +447,7 @@ extern "C" int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, i
                                        int variant, hipStream_t stream) {
   if (M <= 0 || Nout <= 0) return 0;
   if (!use_dma_kernel()) return 1;
-  if (T <= 0 || Cin <= 0 || M % T || ldw < 5 * Cin || (ldw * 2) % 16 || (ldx * 2) % 16 || variant < 0 || variant > 1) return -1;
+  if (T <= 0 || Cin <= 0 || M % T || ldw < 5 * Cin || (ldw * 2) % 16 || (ldx * 2) % 16 || variant < 0 || variant > 2) return -1;
   if (X2 == nullptr) Csplit = Cin;
   if (Csplit > Cin || ldx < Csplit || (X2 && (ldx2 < Cin - Csplit || (ldx2 * 2) % 16))) return -1;
   GemmFwdParams p;

@@ -880,7 +880,7 @@ def _conv_block_fused(x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w,
                            _stream())
 
     sig = ("convgn", M, cin, O, t_in, G, mode, need_y, x2 is not None)
-    variant = _tuned_tile(sig, (0, 1), launch)
+    variant = _tuned_tile(sig, (0, 1, 2), launch)
     if variant < 0:          # not tuned (graph capture of an unseen shape / tuning disabled): fill the chip
         variant = 0 if (-(-n_seq // (192 // t_in))) * (O // 128) >= 200 else 1
     g = _Geom()

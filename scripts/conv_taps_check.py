@@ -63,7 +63,7 @@ for N, T, ci, co, cnt in shapes:
     dxref = Fn.conv_transpose1d(gr, wr, padding=2).permute(0, 2, 1).reshape(M, ci)
     line = f"N={N:4d} T={T:2d} {ci:4d}->{co:4d}:"
     best_old = [1e9, 1e9]
-    for tile in list(range(14)) + [14, 15]:
+    for tile in list(range(14)) + [14, 15, 16]:
         y = torch.full((M, co), 7.0, dtype=torch.bfloat16, device=dev)
         rc = fwd(x, Wf, y, M, T, ci, co, tile, bias, rowbias)
         if rc != 0:
