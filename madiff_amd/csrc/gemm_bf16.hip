@@ -641,31 +641,49 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_taps_bf16_kernel(GemmWgradP
     if (issued < nsteps) { issue(ibuf, s_begin + issued); ++issued; if (++ibuf == D) ibuf = 0; }
     const unsigned char* B0 = &smem[buf * BUF_BYTES];
     if (++buf == D) buf = 0;
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      bf16x8 a[MI];
+    // Fragment pipeline inside a stage: the X fragments of tap k+1 (or, after the last tap, the dY and tap-0 fragments of
+    // the next 32-row chunk) are read while the MFMAs of tap k run.  sched_barrier(0) keeps hipcc from sinking each
+    // read down to its first use, which would expose one LDS latency per group of MI*NJ MFMAs.
+    auto load_a = [&](bf16x8 (&a)[MI], const int q) {
 #pragma unroll
       for (int i = 0; i < MI; i++) {
         s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (yoff[q][0] ^ (i << 5))));
         s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (yoff[q][1] ^ (i << 5))));
         a[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
       }
+    };
+    auto load_b = [&](bf16x8 (&b)[NJ], const int q, const int k) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (xoff[q][0][k] ^ (j << 5))));
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (xoff[q][1][k] ^ (j << 5))));
+        b[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    };
+    bf16x8 a[2][MI], b[2][NJ];
+    load_a(a[0], 0);
+    load_b(b[0], 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
 #pragma unroll
       for (int k = 0; k < TAPS; k++) {
-        bf16x8 b[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (xoff[q][0][k] ^ (j << 5))));
-          s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (xoff[q][1][k] ^ (j << 5))));
-          b[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        const int t = q * TAPS + k;                 // position in the stage: fragments alternate between two register sets
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < TAPS) {
+          load_b(b[(t + 1) & 1], q, k + 1);
+        } else if (q + 1 < NQ) {
+          load_a(a[(q + 1) & 1], q + 1);
+          load_b(b[(t + 1) & 1], q + 1, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MI; i++)
 #pragma unroll
           for (int j = 0; j < NJ; j++)
-            acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[k][i][j], 0, 0, 0);
+            acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q & 1][i], b[t & 1][j], acc[k][i][j], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 
 #pragma unroll
