@@ -385,7 +385,13 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
   constexpr int YCH = BO / 8, XCH = BC / 8;              // 16-byte chunks per tile row
   constexpr int YP = YCH / 4, XP = XCH / 4;              // DMA pieces (1 KB) per wave: wave w fills rows [16w, 16w+16)
   constexpr int YRP = 64 / YCH, XRP = 64 / XCH;          // rows per piece
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF_BYTES];   // [buf][dY tile | X tile]
+  // D LDS stages ([dY tile | X tile] each): three for every tile but 128x128 (two workgroups per CU must still fit).
+  // Same pipeline as the all-taps kernel below: counted vmcnt wait for the stage's own pieces, one raw barrier, the
+  // stage D-1 ahead re-issued into the buffer every wave has just finished with.  The small layers this kernel serves
+  // run a handful of K-steps per workgroup and are bound by the DMA latency of each step, not by its MFMAs.
+  constexpr int D = (BO + BC >= 256) ? 2 : 3;
+  constexpr int PIECES = YP + XP;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[D * BUF_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wc = wave & 1;
   const int n0 = blockIdx.x * BO;
@@ -449,13 +455,18 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
   const int tq = fr >> 2, tp = fr & 3;
   typedef s16x4 __attribute__((address_space(3))) * lds_p;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  issue(0, s_begin);
-  wait_vmcnt<0>();                 // the DMA is issued through asm: the compiler adds no vmcnt wait of its own
-  __syncthreads();
-  for (int s = s_begin; s < s_end; s++) {
-    const int buf = (s - s_begin) & 1;
-    if (s + 1 < s_end) issue(buf ^ 1, s + 1);
+  const int nsteps = s_end - s_begin;
+  int issued = 0, ibuf = 0, buf = 0;
+#pragma unroll
+  for (int d = 0; d < D - 1; d++)
+    if (d < nsteps) { issue(ibuf, s_begin + issued); ++issued; if (++ibuf == D) ibuf = 0; }
+  for (int s = 0; s < nsteps; s++) {
+    if (s + D - 1 <= nsteps) wait_vmcnt<(D - 2) * PIECES>();   // stage s landed, D-2 younger stages still in flight
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (issued < nsteps) { issue(ibuf, s_begin + issued); ++issued; if (++ibuf == D) ibuf = 0; }
     const unsigned char* Ys = &smem[buf * BUF_BYTES];
+    if (++buf == D) buf = 0;
     const unsigned char* Xs = Ys + Y_BYTES;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
@@ -482,8 +493,6 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
         for (int j = 0; j < NJ; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    wait_vmcnt<0>();               // stage s+1 landed (own pieces), then everyone's
-    __syncthreads();
   }
 
 #pragma unroll
