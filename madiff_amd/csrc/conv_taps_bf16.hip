@@ -60,7 +60,7 @@ struct GnEpi {
 
 // D = 3 / 4: one barrier per (chunk, tap) step.  D = 5: one barrier per TWO steps (the ring then holds the three stages a
 // double-step reads or prefetches from plus the two in flight; needs an even number of channel chunks).
-template <int WM, bool WT, int D, bool GN>
+template <int WM, bool WT, int D, bool GN, int VPL = 0>
 __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams p, int rows_used, int shift0, int shift_step,
                                                                   GnEpi ge) {
   static_assert(!(GN && WT), "the GroupNorm epilogue belongs to the forward kernel");
@@ -306,14 +306,41 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   }
 
   if constexpr (GN) {
-    // ---- fused GroupNorm + Mish epilogue.  (1) accumulators + conv bias -> fp32 LDS image of the whole tile;
-    // (2) a wave takes whole sequences: lane = (row r0 = lane / 16, 8-channel vector cv = lane % 16), iteration i covers
-    // row r0 + 4 i; group statistics are butterfly sums over the lane bits inside a group (as gn_mish_fwd_rb_kernel);
-    // (3) y (pre-norm, for backward) and the activated output leave as 16-byte vectors.
+    // ---- fused GroupNorm + Mish epilogue.  (0) every global operand of the epilogue (row bias / residual of all the
+    // sequences this wave will normalise) is requested first, so its latency hides behind (1) accumulators + conv bias
+    // -> fp32 LDS image of the whole tile; (2) a wave takes whole sequences: lane = (row r0 = lane / 16, 8-channel
+    // vector cv = lane % 16), iteration i covers row r0 + 4 i (VPL = ceil(T / 4) iterations, a template parameter so
+    // that all SEQ = 8 / VPL sequences of a wave live in registers at once and their butterflies interleave); group
+    // statistics are butterfly sums over the lane bits inside a group (as gn_mish_fwd_rb_kernel); (3) y (pre-norm,
+    // for backward) and the activated output leave as 16-byte vectors.
     constexpr int LDG = 132;
-    constexpr int VMAX = 8;                  // T <= 32
+    constexpr int SEQ = 8 / VPL;             // sequences per wave (launcher: ceil(spt / NW) <= SEQ)
+    static_assert(VPL >= 1 && SEQ >= 1, "VPL in 1..8");
     static_assert(BM * LDG * 4 <= 2 * A_BYTES + D * W_BYTES, "tile image must fit the operand LDS");
     float* tile = (float*)smem;
+    const int cv = lane & 15, r0 = lane >> 4, c0 = n0 + cv * 8;
+    const int Cg = p.Nout / ge.G;
+    const float inv_e = 1.f / (float)(T * Cg);
+    const int spt = rows_used / T, n_seq = p.M / T;
+    bf16x8 rs[SEQ][VPL];
+    float rb[SEQ][8];
+    float gmv[8], btv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { gmv[e] = ge.gamma[c0 + e]; btv[e] = ge.beta[c0 + e]; }
+#pragma unroll
+    for (int sl = 0; sl < SEQ; sl++) {
+      const int sq = wave + sl * NW, n = blockIdx.x * spt + sq;
+      const bool live = sq < spt && n < n_seq;
+#pragma unroll
+      for (int e = 0; e < 8; e++) rb[sl][e] = (live && ge.mode == 1) ? ge.rowbias[(size_t)n * ge.ldrb + c0 + e] : 0.f;
+      if (ge.mode == 2) {
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+          const int r = r0 + 4 * i;
+          if (live && r < T) rs[sl][i] = *(const bf16x8*)(ge.res + ((size_t)n * T + r) * ge.ldr + c0);
+        }
+      }
+    }
     __syncthreads();                         // every wave is done with the operand tiles; no DMA is outstanding
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
@@ -325,80 +352,87 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
         for (int r = 0; r < 4; r++) tile[(wm * 48 + i * 16 + fq * 4 + r) * LDG + col] = acc[i][j][r] + bv;
     }
     __syncthreads();
-    const int cv = lane & 15, r0 = lane >> 4, c0 = n0 + cv * 8;
-    const int Cg = p.Nout / ge.G;
-    const float inv_e = 1.f / (float)(T * Cg);
-    const int spt = rows_used / T, n_seq = p.M / T;
-    float gmv[8], btv[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) { gmv[e] = ge.gamma[c0 + e]; btv[e] = ge.beta[c0 + e]; }
     bf16_t* Y = (bf16_t*)p.C;
-    for (int sq = wave; sq < spt; sq += NW) {
-      const int n = blockIdx.x * spt + sq;
-      if (n >= n_seq) break;
-      const size_t rbase = (size_t)n * T;
-      float v[VMAX][8];
-      bf16x8 rs[VMAX];
-      float rb[8];
+    float v[SEQ][VPL][8];
+    float sum[SEQ], sqs[SEQ], mean[SEQ], rstd[SEQ];
 #pragma unroll
-      for (int i = 0; i < VMAX; i++) {
+    for (int sl = 0; sl < SEQ; sl++) {
+      const int sq = wave + sl * NW, n = blockIdx.x * spt + sq;
+      const bool live = sq < spt && n < n_seq;
+      sum[sl] = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
         const int r = r0 + 4 * i;
-        if (r < T) {
-          if (ge.mode == 2) rs[i] = *(const bf16x8*)(ge.res + (rbase + r) * ge.ldr + c0);
+        if (live && r < T) {
           const f32x4 a = *(const f32x4*)&tile[(sq * T + r) * LDG + cv * 8];
           const f32x4 b = *(const f32x4*)&tile[(sq * T + r) * LDG + cv * 8 + 4];
-          v[i][0] = a[0]; v[i][1] = a[1]; v[i][2] = a[2]; v[i][3] = a[3];
-          v[i][4] = b[0]; v[i][5] = b[1]; v[i][6] = b[2]; v[i][7] = b[3];
-        }
-      }
+          v[sl][i][0] = a[0]; v[sl][i][1] = a[1]; v[sl][i][2] = a[2]; v[sl][i][3] = a[3];
+          v[sl][i][4] = b[0]; v[sl][i][5] = b[1]; v[sl][i][6] = b[2]; v[sl][i][7] = b[3];
 #pragma unroll
-      for (int e = 0; e < 8; e++) rb[e] = ge.mode == 1 ? ge.rowbias[(size_t)n * ge.ldrb + c0 + e] : 0.f;
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < VMAX; i++)
-        if (r0 + 4 * i < T) {
-#pragma unroll
-          for (int e = 0; e < 8; e++) sum += v[i][e];
+          for (int e = 0; e < 8; e++) sum[sl] += v[sl][i][e];
           if (ge.write_y) {
             bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; e++) o[e] = (bf16_t)v[i][e];
-            *(bf16x8*)(Y + (rbase + r0 + 4 * i) * p.ldc + c0) = o;
+            for (int e = 0; e < 8; e++) o[e] = (bf16_t)v[sl][i][e];
+            *(bf16x8*)(Y + ((size_t)n * T + r) * p.ldc + c0) = o;
           }
-        }
-      // lanes of one group differ in bits [0, gv_log2) (vector inside the group) and bits 4, 5 (row)
-      for (int b = 0; b < ge.gv_log2; b++) sum += __shfl_xor(sum, 1 << b, 64);
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float mean = sum * inv_e;
-      float sqs = 0.f;
+        } else {
 #pragma unroll
-      for (int i = 0; i < VMAX; i++)
-        if (r0 + 4 * i < T) {
-#pragma unroll
-          for (int e = 0; e < 8; e++) { const float d = v[i][e] - mean; sqs += d * d; }
+          for (int e = 0; e < 8; e++) v[sl][i][e] = 0.f;
         }
-      for (int b = 0; b < ge.gv_log2; b++) sqs += __shfl_xor(sqs, 1 << b, 64);
-      sqs += __shfl_xor(sqs, 16, 64);
-      sqs += __shfl_xor(sqs, 32, 64);
-      const float rstd = rsqrtf(sqs * inv_e + ge.eps);
+      }
+    }
+    // lanes of one group differ in bits [0, gv_log2) (vector inside the group) and bits 4, 5 (row)
+    for (int b = 0; b < ge.gv_log2; b++) {
+#pragma unroll
+      for (int sl = 0; sl < SEQ; sl++) sum[sl] += __shfl_xor(sum[sl], 1 << b, 64);
+    }
+#pragma unroll
+    for (int sl = 0; sl < SEQ; sl++) {
+      sum[sl] += __shfl_xor(sum[sl], 16, 64);
+      sum[sl] += __shfl_xor(sum[sl], 32, 64);
+      mean[sl] = sum[sl] * inv_e;
+      const int sq = wave + sl * NW, n = blockIdx.x * spt + sq;
+      const bool live = sq < spt && n < n_seq;
+      sqs[sl] = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; i++)
+        if (live && r0 + 4 * i < T) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) { const float d = v[sl][i][e] - mean[sl]; sqs[sl] += d * d; }
+        }
+    }
+    for (int b = 0; b < ge.gv_log2; b++) {
+#pragma unroll
+      for (int sl = 0; sl < SEQ; sl++) sqs[sl] += __shfl_xor(sqs[sl], 1 << b, 64);
+    }
+#pragma unroll
+    for (int sl = 0; sl < SEQ; sl++) {
+      sqs[sl] += __shfl_xor(sqs[sl], 16, 64);
+      sqs[sl] += __shfl_xor(sqs[sl], 32, 64);
+      rstd[sl] = rsqrtf(sqs[sl] * inv_e + ge.eps);
+      const int sq = wave + sl * NW, n = blockIdx.x * spt + sq;
+      const bool live = sq < spt && n < n_seq;
+      if (!live) continue;
       if (ge.mean && r0 == 0 && (cv & ((1 << ge.gv_log2) - 1)) == 0) {
         const int g = c0 / Cg;
-        ge.mean[(size_t)n * ge.G + g] = mean;
-        ge.rstd[(size_t)n * ge.G + g] = rstd;
+        ge.mean[(size_t)n * ge.G + g] = mean[sl];
+        ge.rstd[(size_t)n * ge.G + g] = rstd[sl];
       }
       float sc[8], sh[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { sc[e] = rstd * gmv[e]; sh[e] = btv[e] - mean * sc[e]; }
+      for (int e = 0; e < 8; e++) { sc[e] = rstd[sl] * gmv[e]; sh[e] = btv[e] - mean[sl] * sc[e]; }
 #pragma unroll
-      for (int i = 0; i < VMAX; i++)
-        if (r0 + 4 * i < T) {
+      for (int i = 0; i < VPL; i++) {
+        const int r = r0 + 4 * i;
+        if (r < T) {
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; e++)
-            o[e] = (bf16_t)(mish_f(v[i][e] * sc[e] + sh[e]) + (ge.mode == 2 ? (float)rs[i][e] : rb[e]));
-          *(bf16x8*)(ge.out + (rbase + r0 + 4 * i) * ge.ldo + c0) = o;
+            o[e] = (bf16_t)(mish_f(v[sl][i][e] * sc[e] + sh[e]) + (ge.mode == 2 ? (float)rs[sl][i][e] : rb[sl][e]));
+          *(bf16x8*)(ge.out + ((size_t)n * T + r) * ge.ldo + c0) = o;
         }
+      }
     }
     return;
   }
@@ -537,12 +571,24 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_
   const int spt = BM / T, rows_used = spt * T;
   const int n_seq = p.M / T;
   dim3 grid((n_seq + spt - 1) / spt, p.Nout / 128);
-  if (variant == 2)
-    hipLaunchKernelGGL((conv_taps_bf16_kernel<4, false, 5, true>), grid, dim3(512), 0, stream, p, rows_used, -2, 1, ge);
-  else if (variant == 0)
-    hipLaunchKernelGGL((conv_taps_bf16_kernel<4, false, 4, true>), grid, dim3(512), 0, stream, p, rows_used, -2, 1, ge);
-  else
-    hipLaunchKernelGGL((conv_taps_bf16_kernel<2, false, 3, true>), grid, dim3(256), 0, stream, p, rows_used, -2, 1, ge);
+  // epilogue geometry: VPL = ceil(T / 4) row iterations per lane, 8 / VPL sequences per wave must cover the tile's share
+  const int vpl = (T + 3) / 4, nw = variant == 1 ? 4 : 8;
+  if ((spt + nw - 1) / nw > 8 / vpl) return 1;
+#define CT_GN(WM_, D_, V_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, false, D_, true, V_>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, -2, 1, ge)
+#define CT_GN_VPL(WM_, D_)                                    \
+  switch (vpl) {                                              \
+    case 2: CT_GN(WM_, D_, 2); break;                         \
+    case 3: CT_GN(WM_, D_, 3); break;                         \
+    case 4: CT_GN(WM_, D_, 4); break;                         \
+    case 6: CT_GN(WM_, D_, 6); break;                         \
+    case 7: CT_GN(WM_, D_, 7); break;                         \
+    default: return 1;                                        \
+  }
+  if (variant == 2) { CT_GN_VPL(4, 5) }
+  else if (variant == 1) { CT_GN_VPL(2, 3) }
+  else return 1;               // (the 4-deep-ring form of the 192-row tile has no fused epilogue: use variant 2)
+#undef CT_GN_VPL
+#undef CT_GN
   MADIFF_CHECK_LAUNCH();
   return 0;
 }
