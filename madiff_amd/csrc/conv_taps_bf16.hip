@@ -382,6 +382,8 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
         }
       }
     }
+    // (explicit fmaf below: left to -ffp-contract, the unrolled sequence slots got different contractions, so a
+    // sequence's statistics depended by an ulp on its position in the tile)
     // lanes of one group differ in bits [0, gv_log2) (vector inside the group) and bits 4, 5 (row)
     for (int b = 0; b < ge.gv_log2; b++) {
 #pragma unroll
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       for (int i = 0; i < VPL; i++)
         if (live && r0 + 4 * i < T) {
 #pragma unroll
-          for (int e = 0; e < 8; e++) { const float d = v[sl][i][e] - mean[sl]; sqs[sl] += d * d; }
+          for (int e = 0; e < 8; e++) { const float d = v[sl][i][e] - mean[sl]; sqs[sl] = __builtin_fmaf(d, d, sqs[sl]); }
         }
     }
     for (int b = 0; b < ge.gv_log2; b++) {
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       }
       float sc[8], sh[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { sc[e] = rstd[sl] * gmv[e]; sh[e] = btv[e] - mean[sl] * sc[e]; }
+      for (int e = 0; e < 8; e++) { sc[e] = rstd[sl] * gmv[e]; sh[e] = __builtin_fmaf(-mean[sl], sc[e], btv[e]); }
 #pragma unroll
       for (int i = 0; i < VPL; i++) {
         const int r = r0 + 4 * i;
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; e++)
-            o[e] = (bf16_t)(mish_f(v[sl][i][e] * sc[e] + sh[e]) + (ge.mode == 2 ? (float)rs[sl][i][e] : rb[sl][e]));
+            o[e] = (bf16_t)(mish_f(__builtin_fmaf(v[sl][i][e], sc[e], sh[e])) + (ge.mode == 2 ? (float)rs[sl][i][e] : rb[sl][e]));
           *(bf16x8*)(ge.out + ((size_t)n * T + r) * ge.ldo + c0) = o;
         }
       }

@@ -250,7 +250,7 @@ class GaussianDiffusion(nn.Module):
                 # step serves every iteration.  Capture does not execute, hence the replay right after.
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with ops.graph_capture(graph):
                     self._denoise_step(st, returns, env_ts, batch_size, t_len)
                 graph.replay()
             else:

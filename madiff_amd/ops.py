@@ -294,6 +294,21 @@ def _timed(name: str, flops: float, launch):
     TIMER.records.append((used if isinstance(used, str) else name, flops, e0, e1))
 
 
+def graph_capture(graph):
+    """torch.cuda.graph(graph) for the train-step and sampler captures.  With an RCCL process group alive, torch's
+    watchdog thread polls the completion events of recent collectives; under the default capture mode ("global") such a
+    call from another thread while this thread captures is an error that ends in abort() (seen on the 1-rank RCCL test:
+    the process died at a random line of the captured step).  So: let the watchdog retire the finished collectives first
+    (device idle + a few of its poll intervals), and capture in "thread_local" mode, which restricts only the capturing
+    thread.  Kernels launched by the autograd thread onto the capturing stream are captured in either mode."""
+    import time
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        time.sleep(0.5)
+    return torch.cuda.graph(graph, capture_error_mode="thread_local")
+
+
 FIRST_TAPS_TILE = 14      # variant ids >= this are the all-taps k5 kernel (csrc/conv_taps_bf16.hip)
 
 

@@ -387,7 +387,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         if self.dp:
             opt.begin_graph_capture()
-        with torch.cuda.graph(self.graph):
+        with ops.graph_capture(self.graph):
             self.loss, self.infos = self._body(captured=True)
         if self.dp:
             assert sorted(opt._graph_order) == list(range(len(opt.buckets))), "a gradient bucket never completed"

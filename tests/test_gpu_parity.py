@@ -272,7 +272,15 @@ def test_full_size_properties():
     x = batch["x"][..., 5:].contiguous()
     t = torch.randint(0, 200, (256,), device=dev)
     perm = torch.randperm(256, device=dev)
-    with torch.no_grad():
-        y = net(x, t, returns=batch["returns"], use_dropout=False)
-        yp = net(x[perm], t[perm], returns=batch["returns"][perm], use_dropout=False)
-    assert rel_err(yp.cpu(), y[perm].cpu()) < 1e-6          # batch elements are independent
+    # batch elements are independent: exact in the fp32 build; in the bf16 build the same up to isolated one-ulp bf16
+    # flips (each tile slot of a fused kernel is its own unrolled code) that the following layers spread
+    from madiff_amd import ops
+    try:
+        for prec, tol in (("bf16", 1e-2), ("fp32", 1e-6)):
+            ops.set_precision(prec)
+            with torch.no_grad():
+                y = net(x, t, returns=batch["returns"], use_dropout=False)
+                yp = net(x[perm], t[perm], returns=batch["returns"][perm], use_dropout=False)
+            assert rel_err(yp.cpu(), y[perm].cpu()) < tol, prec
+    finally:
+        ops.set_precision("bf16")
