@@ -25,31 +25,63 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-A, T, F_OBS, ACT, K_DIFF, BATCH = 4, 24, 16, 5, 200, 256
+# The headline workload is BASELINE.json configs[1] ("tag"); --workload selects the other named shapes for
+# the per-shape table in DESIGN.md.  T = horizon + history_horizon; gf = dense forward GFLOP per sample.
+WORKLOADS = {
+    "tag": dict(A=4, T=24, HH=0, F_OBS=16, ACT=5, DISCRETE=False, NUM_ACTIONS=0, gf=3.295,
+                desc="MADiff-D MPE simple_tag denoiser train step: 4 agents, T=24, F=16, act 5 (BASELINE.json configs[1])"),
+    "spread": dict(A=3, T=24, HH=0, F_OBS=18, ACT=5, DISCRETE=False, NUM_ACTIONS=0, gf=2.471,
+                   desc="MPE simple_spread: 3 agents, T=24, F=18, act 5 (BASELINE.json configs[0] shape)"),
+    "ant": dict(A=4, T=28, HH=18, F_OBS=54, ACT=2, DISCRETE=False, NUM_ACTIONS=0, gf=3.848,
+                desc="MA-Mujoco 4ant: 4 agents, horizon 10 + history 18 = T 28, F=54 (declared synthetic), act 2 "
+                     "(BASELINE.json configs[2] shape)"),
+    "smac": dict(A=8, T=24, HH=20, F_OBS=88, ACT=1, DISCRETE=True, NUM_ACTIONS=14, gf=6.614,
+                 desc="SMAC 8m: 8 agents, horizon 4 + history 20 = T 24, F=88, 14 discrete actions with legal-action "
+                      "masking (BASELINE.json configs[3] shape)"),
+}
+A, T, HH, F_OBS, ACT, DISCRETE, NUM_ACTIONS = 4, 24, 0, 16, 5, False, 0
+K_DIFF, BATCH = 200, 256
 FWD_GF_PER_SAMPLE = 3.295          # SURVEY.md section 8d, A=4, T=24, F=16 (dense fwd FLOPs / sample)
+WORKLOAD_DESC = WORKLOADS["tag"]["desc"]
 MFMA_BF16_PEAK_TF = 2500.0         # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+def select_workload(name, batch):
+    global A, T, HH, F_OBS, ACT, DISCRETE, NUM_ACTIONS, FWD_GF_PER_SAMPLE, WORKLOAD_DESC, BATCH
+    w = WORKLOADS[name]
+    A, T, HH, F_OBS, ACT, DISCRETE, NUM_ACTIONS = (w[k] for k in ("A", "T", "HH", "F_OBS", "ACT", "DISCRETE", "NUM_ACTIONS"))
+    FWD_GF_PER_SAMPLE, WORKLOAD_DESC, BATCH = w["gf"], w["desc"], batch
+
+
 def synthetic_batch(batch, device, seed):
-    """SURVEY.md 8d synthetic inputs: x ~ U(-1,1), first observation conditioned, loss mask 0 at t=hh for visible agents."""
+    """SURVEY.md 8d synthetic inputs: x ~ U(-1,1) (discrete: column 0 = action id), history + current observation
+    conditioned (all agents visible: t < hh + 1), loss mask 1 for t >= hh and 0 at t = hh, legal actions Bernoulli(0.7)
+    with the taken action forced legal."""
     g = torch.Generator().manual_seed(seed)
     x = torch.rand(batch, T, A, ACT + F_OBS, generator=g) * 2 - 1
     masks = torch.zeros(batch, T, A, F_OBS, dtype=torch.bool)
-    masks[:, :1] = True
-    loss_masks = torch.ones(batch, T, A, 1, dtype=torch.float64)
-    loss_masks[:, 0] = 0.0
+    masks[:, :HH + 1] = True
+    loss_masks = torch.zeros(batch, T, A, 1, dtype=torch.float64)
+    loss_masks[:, HH + 1:] = 1.0
     b = {"x": x, "cond": {"x": x[..., ACT:].clone(), "masks": masks}, "loss_masks": loss_masks,
          "attention_masks": torch.ones(batch, T, A, 1, dtype=torch.float64),
          "returns": torch.rand(batch, 1, A, generator=g)}
+    if DISCRETE:
+        act = torch.randint(0, NUM_ACTIONS, (batch, T, A), generator=g)
+        x[..., 0] = act.float()
+        legal = (torch.rand(batch, T, A, NUM_ACTIONS, generator=g) < 0.7).float()
+        legal.scatter_(-1, act[..., None], 1.0)
+        b["legal_actions"] = legal
     mv = lambda v: {k: mv(u) for k, u in v.items()} if isinstance(v, dict) else v.to(device)  # noqa: E731
     return mv(b)
 
 
 def build(device):
     import diffuser.models as DM
-    net = DM.SharedConvAttentionDeconv(horizon=T, transition_dim=F_OBS, dim=128, history_horizon=0, dim_mults=(1, 4, 8),
+    net = DM.SharedConvAttentionDeconv(horizon=T, transition_dim=F_OBS, dim=128, history_horizon=HH, dim_mults=(1, 4, 8),
                                        n_agents=A, returns_condition=True, condition_dropout=0.25)
-    dif = DM.GaussianDiffusion(net, n_agents=A, horizon=T, history_horizon=0, observation_dim=F_OBS, action_dim=ACT,
+    dif = DM.GaussianDiffusion(net, n_agents=A, horizon=T - HH, history_horizon=HH, observation_dim=F_OBS, action_dim=ACT,
+                               discrete_action=DISCRETE, num_actions=NUM_ACTIONS,
                                n_timesteps=K_DIFF, returns_condition=True, condition_guidance_w=1.2, hidden_dim=256,
                                clip_denoised=True, predict_epsilon=True, share_inv=True).to(device)
     for a in net.self_attn:
@@ -89,15 +121,16 @@ def cpu_baseline(seconds_budget=30.0):
     cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
     torch.set_num_threads(cores)
     dcfg = O.DenoiserCfg(horizon=T, transition_dim=F_OBS, dim=128, dim_mults=(1, 4, 8), n_agents=A,
-                         returns_condition=True, condition_dropout=0.25)
-    c = O.DiffusionCfg(A, T, 0, F_OBS, ACT, K_DIFF, hidden_dim=256, returns_condition=True)
+                         returns_condition=True, condition_dropout=0.25, history_horizon=HH)
+    c = O.DiffusionCfg(A, T - HH, HH, F_OBS, ACT, K_DIFF, hidden_dim=256, returns_condition=True,
+                       discrete_action=DISCRETE, num_actions=NUM_ACTIONS)
     shapes = {**{"model." + k: v for k, v in O.denoiser_param_shapes(dcfg).items()}, **O.inv_param_shapes(c)}
     params = {k: O.closed_form_param(k, s).requires_grad_(True) for k, s in shapes.items()}
     live = [p for k, p in params.items() if not k.startswith("model.self_attn.3.")]
     opt = torch.optim.Adam(live, lr=2e-4)
     sched = O.DDPMSchedule(K_DIFF)
     nb = 64
-    batch = O.synthetic_batch(nb, T, A, F_OBS, ACT, 0, seed=0)
+    batch = O.synthetic_batch(nb, T, A, F_OBS, ACT, HH, discrete=DISCRETE, num_actions=NUM_ACTIONS, seed=0)
     g = torch.Generator().manual_seed(0)
 
     def one_step():
@@ -106,7 +139,7 @@ def cpu_baseline(seconds_budget=30.0):
         dm = (torch.rand(nb, A, 1, generator=g) < 0.75).float()
         opt.zero_grad()
         loss, _, _ = O.diffusion_loss(params, dcfg, c, sched, batch["x"], batch["cond"], batch["loss_masks"], t, noise,
-                                      batch["returns"], dm)
+                                      batch["returns"], dm, **({"legal_actions": batch["legal_actions"]} if DISCRETE else {}))
         loss.backward()
         opt.step()
 
@@ -132,7 +165,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="single-GPU: issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--sample-batch", type=int, default=1024,
                     help="episodes sampled per GPU (BASELINE.json configs[4]: 8192 episodes over 8 GPUs = 1024 per GPU)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="tag",
+                    help="named shape (default: BASELINE.json configs[1], the headline workload)")
+    ap.add_argument("--batch", type=int, default=256, help="trajectory windows per GPU per optimizer step")
     args = ap.parse_args()
+    select_workload(args.workload, args.batch)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -253,8 +290,7 @@ def main():
             "metric": "denoiser train samples/sec", "value": train_sps, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "MADiff-D MPE simple_tag denoiser train step: 4 agents, T=24, F=16, act 5, K=200, "
-                                   "dim 128 x [1,4,8], batch 256 per GPU (BASELINE.json configs[1])",
+            "config": {"workload": WORKLOAD_DESC + f"; K={K_DIFF}, dim 128 x [1,4,8], batch {BATCH} per GPU",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}",
                        "step": "loss fwd + bwd + bucketed all-reduce + fused Adam (+EMA every 10)",
                        "launch": ("one hipGraph replay per step" if not opt.dp else
