@@ -54,14 +54,36 @@ def _stream() -> int:
 AUX_STREAMS: dict = {}
 
 
-def aux_stream(device) -> "torch.cuda.Stream":
-    """The one auxiliary stream per device on which independent branches of a step are issued (the data-parallel
-    optimizer waits on it, besides the current stream, before it reduces a gradient bucket)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def aux_stream(device, name: str = "branch") -> "torch.cuda.Stream":
+    """The auxiliary streams (one per device and name) on which independent branches of a step are issued: "branch" = the
+    inverse-dynamics loss, "wgrad" = parameter gradients.  The data-parallel optimizer waits on all of them, besides the
+    current stream, before it reduces a gradient bucket, and the optimizer step joins them."""
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), name)
     st = AUX_STREAMS.get(key)
     if st is None:
         st = AUX_STREAMS[key] = torch.cuda.Stream(device=device)
     return st
+
+
+def stream_is_capturing(st) -> bool:
+    with torch.cuda.stream(st):
+        return torch.cuda.is_current_stream_capturing()
+
+
+def join_aux_streams(target=None):
+    """Make `target` (default: the current stream) wait for everything issued so far on the auxiliary streams.  While
+    `target` is capturing, only the auxiliary streams that have joined the same capture are waited for: an event
+    recorded on a stream outside the capture must not be waited on from inside it (the runtime crashes), and such a
+    stream holds no work of the step being captured anyway."""
+    cur = torch.cuda.current_stream()
+    target = cur if target is None else target
+    capturing = stream_is_capturing(target)
+    for st in AUX_STREAMS.values():
+        if st.cuda_stream == target.cuda_stream:
+            continue
+        if capturing and not stream_is_capturing(st):
+            continue
+        target.wait_stream(st)
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -488,6 +510,7 @@ class GradSink:
     def __init__(self):
         self.views = {}
         self.notify = None
+        self.deferred = None
         self.flat_p = self.flat_g = self.flat_p16 = None
         self.slots = {}          # id(param) -> (weakref, offset, O, K, kind, taps)
         self.shadow_state = {}   # id(param) -> (param._version, _EPOCH_EXT) at which the bf16 shadow was in sync
@@ -508,7 +531,9 @@ class GradSink:
         return ent[1]
 
     def done(self, param):
-        if self.notify is not None:
+        if self.deferred is not None:        # issued on a side stream: announce once the issuing code is back on its stream
+            self.deferred.append(param)
+        elif self.notify is not None:
             self.notify(param)
 
     def _group(self, weights, spec):
@@ -699,12 +724,43 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
         if x2 is not None:
             dx2 = grads[1]
     gw: List[Optional[torch.Tensor]] = [None] * len(weights)
-    gw, gb = _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw)
+    gw, gb = _param_grads_side(g, x, x2, weights, biases, dy, need_w, bias_mode, gw)
     if need_rb:
         drb = torch.empty(n_seq, osum, dtype=torch.float32, device=dy.device)
         lib.call("madiff_seqsum", _dt(), dy.data_ptr(), dy.stride(0), drb.data_ptr(), drb.stride(0), n_seq, t_out,
                  osum, _stream())
     return dx, dx2, drb, gw, gb
+
+
+WGRAD_SIDE_STREAM = os.environ.get("MADIFF_WGRAD_SIDE_STREAM", "1") != "0"
+
+
+def _param_grads_side(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
+    """Parameter gradients of a layer are needed by the optimizer only, the data gradient by the rest of backward: when
+    every result lands in the flat gradient (gradient sink installed), the weight-gradient GEMM and the bias column
+    sums are issued on the "wgrad" auxiliary stream, i.e. as a parallel branch of the (captured) step, so that they fill
+    the compute units the small layers' data-gradient launches leave idle.  Bucket notifications are delivered after
+    returning to the issuing stream (the optimizer's hook then orders the bucket behind every auxiliary stream)."""
+    sink = SINK
+    if not (WGRAD_SIDE_STREAM and dy.is_cuda and sink is not None and sink.deferred is None and TIMER is None
+            and any(need_w) and all(need_w) and sink.grad_matrix(weights, g.spec) is not None
+            and (bias_mode != "colsum" or all(_sink_view(b) is not None for b in biases))):
+        return _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw)
+    cur = torch.cuda.current_stream()
+    side = aux_stream(dy.device, "wgrad")
+    side.wait_stream(cur)
+    sink.deferred = []
+    try:
+        with torch.cuda.stream(side):
+            out = _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw)
+    finally:
+        pending, sink.deferred = sink.deferred, None
+    for t in (dy, x, x2):
+        if t is not None:
+            t.record_stream(side)
+    for p_ in pending:
+        sink.done(p_)
+    return out
 
 
 def _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):

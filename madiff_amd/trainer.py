@@ -192,20 +192,24 @@ class FlatAdamEMA:
             # Capturing a data-parallel step (GraphedTrainStep): no collective goes into the graph.  The bucket's
             # completion becomes a graph-external event node; after each replay the communication stream waits on it and
             # runs the all-reduce eagerly, overlapped with the rest of the replayed backward pass.
+            # The event node goes onto the "wgrad" auxiliary stream (where most members are produced anyway) after that
+            # stream has waited for the issuing stream and the other branches: edges then only ever run INTO the wgrad
+            # branch, which rejoins the main branch once, at the end of the step.  (Joining the branches into the
+            # main stream at every bucket instead made hipStreamEndCapture crash.)
             cur = torch.cuda.current_stream()
-            for st in ops.AUX_STREAMS.values():       # members may have been produced on a parallel branch
-                if st.cuda_stream != cur.cuda_stream:
-                    cur.wait_stream(st)
+            tgt = ops.aux_stream(cur.device, "wgrad") if ops.WGRAD_SIDE_STREAM else cur
+            if tgt.cuda_stream != cur.cuda_stream:
+                tgt.wait_stream(cur)
+            ops.join_aux_streams(tgt)                 # members may have been produced on a parallel branch
             bi = self.buckets.index(b)
-            lib.call("madiff_event_record_external", self._graph_events[bi], cur.cuda_stream)
+            lib.call("madiff_event_record_external", self._graph_events[bi], tgt.cuda_stream)
             self._graph_order.append(bi)
             b["work"] = "graph"
             return
         g = self.flat_g[b["lo"]:b["hi"]]
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
-            for st in ops.AUX_STREAMS.values():      # members of the bucket may have been produced on a side branch
-                self._comm_stream.wait_stream(st)
+            ops.join_aux_streams(self._comm_stream)  # members of the bucket may have been produced on a side branch
             with torch.cuda.stream(self._comm_stream):
                 b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         else:
@@ -284,8 +288,7 @@ class FlatAdamEMA:
         if first:
             self._materialise()
         if self.flat_p.is_cuda:                      # join the parallel branches of the step (ops.aux_stream)
-            for st in ops.AUX_STREAMS.values():
-                torch.cuda.current_stream().wait_stream(st)
+            ops.join_aux_streams()
         self._finish_allreduce()
         self.step_count += 1
         b1, b2 = self.betas
@@ -403,8 +406,7 @@ class GraphedTrainStep:
         loss.backward()
         if captured and self.dp:
             # data parallel: the graph ends with backward; all-reduce and Adam are issued after each replay
-            for st in ops.AUX_STREAMS.values():
-                torch.cuda.current_stream().wait_stream(st)
+            ops.join_aux_streams()
         elif captured:
             self.opt.step(device_state=self.state)      # launches only; host-side counters advance in step()
             self.opt.step_count -= 1

@@ -12,4 +12,4 @@ static void handler(int sig) {
   signal(sig, SIG_DFL);
   raise(sig);
 }
-void install_abrt_trace(void) { signal(SIGABRT, handler); }
+void install_abrt_trace(void) { signal(SIGABRT, handler); signal(SIGSEGV, handler); }
