@@ -168,7 +168,10 @@ int madiff_seqsum(int dtype, const void* x, int ld, float* out, int ldo, long N,
  * arguments; state != NULL (device int[2] = {completed steps, do_ema}): they are derived on the device and state[0] is
  * incremented afterwards (hipGraph replay of a whole train step).  shadow_bf16 != NULL: the bf16 rounding of every
  * updated parameter is written to shadow_bf16[e] (the flat buffer is kept in GEMM layout, so that copy is the packed
- * weight operand of the next step).  zero_grad != 0 clears g after it was consumed (optimizer.zero_grad, :155). */
+ * weight operand of the next step).  zero_grad bit 0: clear g after it was consumed (optimizer.zero_grad, :155); bit 1:
+ * do not advance state[0] after this launch (the step is issued as several slices, one per gradient bucket, overlapped
+ * with backward; only the last call advances).  n == 0 with state != NULL: advance only.  16-byte accesses are used
+ * when every pointer is 16-byte aligned and n % 4 == 0. */
 int madiff_adam_ema(float* p, float* g, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
                     float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta, int* state,
                     void* shadow_bf16, int zero_grad, madiff_stream_t stream);

@@ -234,7 +234,21 @@ __global__ void seqsum_kernel(const T* __restrict__ x, int ld, float* __restrict
 // ema = beta*ema + (1-beta)*p when do_ema == 1, ema = p when do_ema == 2 (the "copy until step 2000" phase).
 // shadow != null: the bf16 copy of the updated parameter is written alongside (the flat buffer is kept in GEMM layout,
 // so this IS the packed forward weight of the next step: no separate pack pass).  zero_grad: g is cleared after use.
-__global__ void adam_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+__device__ __forceinline__ float adam_elem(float& gr_io, float& m_io, float& v_io, float p_in, float lr, float b1, float b2,
+                                          float eps, float bc1, float bc2_sqrt, float grad_scale) {
+  const float gr = gr_io * grad_scale;
+  const float mm = b1 * m_io + (1.f - b1) * gr;
+  const float vv = b2 * v_io + (1.f - b2) * gr * gr;
+  m_io = mm;
+  v_io = vv;
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  return p_in - (lr / bc1) * (mm / denom);
+}
+
+// VEC: 16-byte accesses on every stream (all pointers 16-byte aligned, n % 4 == 0: the flat buffers and their bucket
+// slices are); otherwise one element per access.
+template <bool VEC>
+__global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, float* __restrict__ ema, long n, float lr, float b1, float b2,
                                 float eps, float bc1, float bc2_sqrt, float grad_scale, int do_ema, float ema_beta,
                                 const int* __restrict__ state, bf16_t* __restrict__ shadow, int zero_grad) {
@@ -244,19 +258,52 @@ __global__ void adam_ema_kernel(float* __restrict__ p, float* __restrict__ g, fl
     bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
     do_ema = state[1];
   }
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    float gr = g[e] * grad_scale;
-    if (zero_grad) g[e] = 0.f;
-    float mm = b1 * m[e] + (1.f - b1) * gr;
-    float vv = b2 * v[e] + (1.f - b2) * gr * gr;
-    m[e] = mm;
-    v[e] = vv;
-    float denom = sqrtf(vv) / bc2_sqrt + eps;
-    float pv = p[e] - (lr / bc1) * (mm / denom);
-    p[e] = pv;
-    if (shadow) shadow[e] = (bf16_t)pv;
-    if (do_ema == 1) ema[e] = ema_beta * ema[e] + (1.f - ema_beta) * pv;
-    else if (do_ema == 2) ema[e] = pv;
+  const long stride = (long)gridDim.x * blockDim.x, tid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if constexpr (VEC) {
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    typedef __attribute__((ext_vector_type(4))) bf16_t b4;
+    const long n4 = n >> 2;
+    for (long q = tid; q < n4; q += stride) {
+      f4 gv = ((const f4*)g)[q], mv = ((const f4*)m)[q], vv = ((const f4*)v)[q], pv = ((const f4*)p)[q];
+      f4 ev;
+      if (do_ema == 1) ev = ((const f4*)ema)[q];
+      if (zero_grad) ((f4*)g)[q] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float gg = gv[e], mm = mv[e], v2 = vv[e];
+        pv[e] = adam_elem(gg, mm, v2, pv[e], lr, b1, b2, eps, bc1, bc2_sqrt, grad_scale);
+        mv[e] = mm;
+        vv[e] = v2;
+      }
+      ((f4*)m)[q] = mv;
+      ((f4*)v)[q] = vv;
+      ((f4*)p)[q] = pv;
+      if (shadow) {
+        b4 sv;
+#pragma unroll
+        for (int e = 0; e < 4; e++) sv[e] = (bf16_t)pv[e];
+        ((b4*)shadow)[q] = sv;
+      }
+      if (do_ema == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) ev[e] = ema_beta * ev[e] + (1.f - ema_beta) * pv[e];
+        ((f4*)ema)[q] = ev;
+      } else if (do_ema == 2) {
+        ((f4*)ema)[q] = pv;
+      }
+    }
+  } else {
+    for (long e = tid; e < n; e += stride) {
+      float gr = g[e], mm = m[e], vv = v[e];
+      if (zero_grad) g[e] = 0.f;
+      const float pv = adam_elem(gr, mm, vv, p[e], lr, b1, b2, eps, bc1, bc2_sqrt, grad_scale);
+      m[e] = mm;
+      v[e] = vv;
+      p[e] = pv;
+      if (shadow) shadow[e] = (bf16_t)pv;
+      if (do_ema == 1) ema[e] = ema_beta * ema[e] + (1.f - ema_beta) * pv;
+      else if (do_ema == 2) ema[e] = pv;
+    }
   }
 }
 
@@ -447,12 +494,24 @@ extern "C" int madiff_adam_ema(float* p, float* g, float* m, float* v, float* em
   // state == null: bc1 = 1 - b1^step, bc2s = sqrt(1 - b2^step) and do_ema come from the host (computed in double, as
   // torch.optim.Adam does).  state != null (device int[2] = {completed steps, do_ema}): both are derived on the device
   // and state[0] is incremented afterwards, so the launch pair can live inside a replayed hipGraph.
-  if (n <= 0) return 0;
-  if (!p || !g || !m || !v || (!state && (bc1 <= 0.f || bc2s <= 0.f)) || ((do_ema || state) && !ema && do_ema)) return -1;
-  hipLaunchKernelGGL(adam_ema_kernel, dim3(nblocks(n, 256, 8192)), dim3(256), 0, stream, p, g, m, v, ema, n, lr, b1, b2, eps,
-                     bc1, bc2s, grad_scale, do_ema, ema_beta, (const int*)state, (bf16_t*)shadow_bf16, zero_grad);
-  MADIFF_CHECK_LAUNCH();
-  if (state) {
+  // zero_grad: bit 0 = clear g after use; bit 1 = do NOT advance state[0] after this launch (the optimizer step is issued
+  // as several slices, e.g. one per gradient bucket: only the last call advances).  n == 0 with state: advance only.
+  if (n < 0) return -1;
+  if (n > 0) {
+    if (!p || !g || !m || !v || (!state && (bc1 <= 0.f || bc2s <= 0.f)) || ((do_ema || state) && !ema && do_ema)) return -1;
+    const bool vec = n % 4 == 0 && (((size_t)p | (size_t)g | (size_t)m | (size_t)v | (size_t)ema) % 16) == 0 &&
+                     ((size_t)shadow_bf16 % 8) == 0;
+    if (vec)
+      hipLaunchKernelGGL(adam_ema_kernel<true>, dim3(nblocks(n / 4, 256, 8192)), dim3(256), 0, stream, p, g, m, v, ema, n, lr,
+                         b1, b2, eps, bc1, bc2s, grad_scale, do_ema, ema_beta, (const int*)state, (bf16_t*)shadow_bf16,
+                         zero_grad & 1);
+    else
+      hipLaunchKernelGGL(adam_ema_kernel<false>, dim3(nblocks(n, 256, 8192)), dim3(256), 0, stream, p, g, m, v, ema, n, lr,
+                         b1, b2, eps, bc1, bc2s, grad_scale, do_ema, ema_beta, (const int*)state, (bf16_t*)shadow_bf16,
+                         zero_grad & 1);
+    MADIFF_CHECK_LAUNCH();
+  }
+  if (state && !(zero_grad & 2)) {
     hipLaunchKernelGGL(sampler_advance_kernel, dim3(1), dim3(64), 0, stream, state);
     MADIFF_CHECK_LAUNCH();
   }

@@ -544,7 +544,7 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_wgrad_bf
 // NQ: 32-row chunks per K-step; requires (32*NQ) % T == 0 (T in {2,4,8,16,32} -> NQ 1; T in {3,6,12,24,...} -> NQ 3).
 // ------------------------------------------------------------------------------------------------
 template <int BO, int BC, int TAPS, int NQ, int D>
-__global__ __launch_bounds__(256, 2) void gemm_wgrad_taps_bf16_kernel(GemmWgradParams p) {
+__global__ __launch_bounds__(256, (BO >= 128 ? 1 : 2)) void gemm_wgrad_taps_bf16_kernel(GemmWgradParams p) {
   static_assert(BC == 64, "X tile: 128-byte rows");
   constexpr int KR = 32 * NQ;
   constexpr int MI = BO / 32, NJ = BC / 32;

@@ -50,6 +50,11 @@ class FlatAdamEMA:
         self._comm_stream = None
         self.use_hip = use_hip_kernel
         self.grad_scale = 1.0
+        # overlap: the optimizer step is issued per gradient bucket, as soon as the bucket is complete (single process:
+        # on the "wgrad" auxiliary stream; data parallel: on the communication stream right behind the bucket's
+        # all-reduce), so the HBM-bound Adam/EMA pass runs under the MFMA-bound rest of backward instead of after it
+        self.overlap = os.environ.get("MADIFF_OVERLAP_ADAM", "1") != "0"
+        self._announced = None           # (do_ema, device_state) of the step whose backward is running (begin_step)
 
     # ------------------------------------------------------------------ setup after the first backward
     def _materialise(self):
@@ -149,8 +154,9 @@ class FlatAdamEMA:
             for i in b["members"]:
                 self._bucket_of[i] = b
         self._index = {id(p): i for i, p in enumerate(self.params)}
-        if self.dp:
-            if dev.type == "cuda":
+        hooked = self.dp or (self.overlap and self.use_hip)
+        if hooked:
+            if self.dp and dev.type == "cuda":
                 self._comm_stream = torch.cuda.Stream(device=dev)
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -167,7 +173,7 @@ class FlatAdamEMA:
                     kind, taps, O, I, ipad = geom
                     sink.register_matrix(p, o, O, taps * ipad, kind, taps)
                     sink.shadow_state[id(p)] = (p._version, ops._EPOCH_EXT)
-            if self.dp:
+            if hooked:
                 hooks = [self._make_hook(i) for i in range(len(self.params))]
                 sink.notify = lambda p: hooks[self._index[id(p)]](p)
             ops.SINK = sink
@@ -187,7 +193,36 @@ class FlatAdamEMA:
                 self._launch_bucket(b)
         return hook
 
+    def begin_step(self, do_ema: int = 0, device_state: Optional[torch.Tensor] = None):
+        """Announce the optimizer step that follows the coming (last micro-batch's) backward pass: with it the bucket
+        hooks may issue that step slice by slice while backward is still running.  step() must then be called with the
+        same arguments.  Without an announcement step() does the whole update itself, as before."""
+        self._announced = (int(do_ema) if self.ema_module is not None else 0, device_state)
+
+    def _adam_slice(self, lo: int, hi: int, do_ema: int, device_state, stream):
+        """Fused Adam/EMA on flat[lo:hi) for the step in progress; never advances the device-side step counter."""
+        b1, b2 = self.betas
+        step = self.step_count + 1
+        e = None if self.flat_ema is None else self.flat_ema.data_ptr() + 4 * lo
+        lib.call("madiff_adam_ema", self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
+                 self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, e, hi - lo, self.lr, b1, b2, self.eps,
+                 1 - b1 ** step, math.sqrt(1 - b2 ** step), self.grad_scale / self.world, do_ema, self.ema_decay,
+                 None if device_state is None else device_state.data_ptr(), self.flat_p16.data_ptr() + 2 * lo, 3,
+                 stream.cuda_stream)
+
     def _launch_bucket(self, b):
+        if not self.dp:
+            # single process: nothing to reduce; the bucket's optimizer slice goes onto the "wgrad" branch
+            if self._announced is None or not self.use_hip:
+                return
+            cur = torch.cuda.current_stream()
+            tgt = ops.aux_stream(cur.device, "wgrad") if ops.WGRAD_SIDE_STREAM else cur
+            if tgt.cuda_stream != cur.cuda_stream:
+                tgt.wait_stream(cur)          # every member's data-gradient launch (it reads the weights) is behind us
+            ops.join_aux_streams(tgt)
+            self._adam_slice(b["lo"], b["hi"], *self._announced, tgt)
+            b["opt"] = True
+            return
         if self._graph_events is not None and torch.cuda.is_current_stream_capturing():
             # Capturing a data-parallel step (GraphedTrainStep): no collective goes into the graph.  The bucket's
             # completion becomes a graph-external event node; after each replay the communication stream waits on it and
@@ -212,6 +247,10 @@ class FlatAdamEMA:
             ops.join_aux_streams(self._comm_stream)  # members of the bucket may have been produced on a side branch
             with torch.cuda.stream(self._comm_stream):
                 b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                if self._announced is not None and self.use_hip and self.overlap:
+                    b["work"].wait()          # orders the communication stream behind the collective (no host wait)
+                    self._adam_slice(b["lo"], b["hi"], *self._announced, self._comm_stream)
+                    b["work"], b["opt"] = "done", True
         else:
             b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
@@ -233,6 +272,7 @@ class FlatAdamEMA:
             for b in self.buckets:
                 b["pending"] = len(b["members"])
                 b["work"] = None
+                b["opt"] = False
 
     # -- data-parallel step replayed from a hipGraph (GraphedTrainStep) ---------------------------------------
     def begin_graph_capture(self):
@@ -247,23 +287,30 @@ class FlatAdamEMA:
         self._graph_order = []
         self.set_sync(True)
 
-    def allreduce_after_replay(self):
+    def allreduce_after_replay(self, do_ema: int = 0):
         """Called right after graph.replay(): start every bucket's all-reduce on the communication stream as soon as
-        its event node inside the running graph has fired; the caller's stream then waits for all of them."""
+        its event node inside the running graph has fired, with the bucket's optimizer slice right behind it (both
+        overlap the rest of the replayed backward); the caller's stream then waits for all of them."""
         assert self._graph_order, "no bucket completion was recorded while capturing"
         cs = self._comm_stream
-        works = []
-        for bi in self._graph_order:
-            b = self.buckets[bi]
-            lib.call("madiff_stream_wait_event", cs.cuda_stream, self._graph_events[bi])
-            with torch.cuda.stream(cs):
-                works.append(dist.all_reduce(self.flat_g[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        with torch.cuda.stream(cs):
-            for w in works:
-                w.wait()
-        torch.cuda.current_stream().wait_stream(cs)
+        if self.ema_module is None:
+            do_ema = 0
+        fused = self.overlap and self.use_hip
         for b in self.buckets:
-            b["work"] = "done"
+            b["opt"] = False
+        with torch.cuda.stream(cs):
+            for bi in self._graph_order:
+                b = self.buckets[bi]
+                lib.call("madiff_stream_wait_event", cs.cuda_stream, self._graph_events[bi])
+                w = dist.all_reduce(self.flat_g[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                w.wait()
+                if fused:
+                    self._adam_slice(b["lo"], b["hi"], do_ema, None, cs)
+                    b["opt"] = True
+                b["work"] = "done"
+        torch.cuda.current_stream().wait_stream(cs)
+        if fused:
+            self._announced = (do_ema, None)
 
     def _finish_allreduce(self):
         if not self.dp:
@@ -276,7 +323,8 @@ class FlatAdamEMA:
                 continue
             if b["work"] is None:      # a bucket whose hooks did not all fire (should not happen) -> reduce now
                 self._launch_bucket(b)
-            b["work"].wait()
+            if b["work"] != "done":
+                b["work"].wait()
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 
@@ -287,25 +335,44 @@ class FlatAdamEMA:
         first = self.flat_p is None
         if first:
             self._materialise()
+            self._announced = None               # (the hooks did not exist during this backward: nothing was issued early)
         if self.flat_p.is_cuda:                      # join the parallel branches of the step (ops.aux_stream)
             ops.join_aux_streams()
         self._finish_allreduce()
-        self.step_count += 1
-        b1, b2 = self.betas
-        bc1 = 1 - b1 ** self.step_count
-        bc2s = math.sqrt(1 - b2 ** self.step_count)
-        scale = self.grad_scale / self.world
         if self.ema_module is None:
             do_ema = 0
+        ann, self._announced = self._announced, None
+        early = [] if first else [b for b in self.buckets if b.get("opt")]
+        if early and ann is not None and (ann[0] != int(do_ema) or
+                                          (ann[1] is None) != (device_state is None)):
+            raise RuntimeError("FlatAdamEMA.step(): arguments differ from what begin_step() announced")
+        b1, b2 = self.betas
+        scale = self.grad_scale / self.world
         if self.use_hip:
-            lib.call("madiff_adam_ema", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                     self.flat_v.data_ptr(), None if self.flat_ema is None else self.flat_ema.data_ptr(), self.total,
-                     self.lr, b1, b2, self.eps, bc1, bc2s, scale, do_ema, self.ema_decay,
-                     None if device_state is None else device_state.data_ptr(),
-                     self.flat_p16.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+            cur = torch.cuda.current_stream()
+            if not early:                            # nothing was issued during backward: one launch over everything
+                lib.call("madiff_adam_ema", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                         self.flat_v.data_ptr(), None if self.flat_ema is None else self.flat_ema.data_ptr(), self.total,
+                         self.lr, b1, b2, self.eps, 1 - b1 ** (self.step_count + 1),
+                         math.sqrt(1 - b2 ** (self.step_count + 1)), scale, do_ema, self.ema_decay,
+                         None if device_state is None else device_state.data_ptr(),
+                         self.flat_p16.data_ptr(), 1, cur.cuda_stream)
+            else:                                    # the remaining slices, then advance the device-side counter once
+                for b in self.buckets:
+                    if not b.get("opt"):
+                        self._adam_slice(b["lo"], b["hi"], int(do_ema), device_state, cur)
+                if device_state is not None:
+                    lib.call("madiff_adam_ema", None, None, None, None, None, 0, self.lr, b1, b2, self.eps, 1.0, 1.0, scale,
+                             0, self.ema_decay, device_state.data_ptr(), None, 1, cur.cuda_stream)
+            for b in self.buckets:
+                b["opt"] = False
+            self.step_count += 1
             self._grads_zeroed = True
             ops.params_changed(by_optimizer=True)
         else:   # host arithmetic for the gloo/CPU tests of the data-parallel machinery only
+            self.step_count += 1
+            bc1 = 1 - b1 ** self.step_count
+            bc2s = math.sqrt(1 - b2 ** self.step_count)
             with torch.no_grad():
                 g = self.flat_g * scale
                 self.flat_m.mul_(b1).add_(g, alpha=1 - b1)
@@ -335,6 +402,8 @@ def train_step(diffusion, opt: FlatAdamEMA, batches, do_ema: int = 0):
     out = None
     for i, batch in enumerate(batches):
         opt.set_sync(i == n - 1)
+        if i == n - 1:
+            opt.begin_step(do_ema)
         loss, infos = diffusion.loss(**batch)
         (loss / n).backward()
         out = (loss.detach(), infos)
@@ -390,6 +459,8 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         if self.dp:
             opt.begin_graph_capture()
+        else:
+            opt.begin_step(0, device_state=self.state)
         with ops.graph_capture(self.graph):
             self.loss, self.infos = self._body(captured=True)
         if self.dp:
@@ -400,8 +471,9 @@ class GraphedTrainStep:
 
     def _body(self, captured: bool = False):
         extra = {} if self.draws is None else {"t": self.draws["t"], "noise": self.draws["noise"]}
+        self.opt.set_sync(True)
         if not captured:
-            self.opt.set_sync(True)
+            self.opt.begin_step(0)
         loss, infos = self.diffusion.loss(**self.batch, dropout_mask=self.mask, **extra)
         loss.backward()
         if captured and self.dp:
@@ -438,7 +510,7 @@ class GraphedTrainStep:
             do_ema = 0
         if self.dp:
             self.graph.replay()
-            self.opt.allreduce_after_replay()
+            self.opt.allreduce_after_replay(do_ema)
             self.opt.step(do_ema)                  # eager fused Adam/EMA (host-side step counter), clears the gradient
             self.opt.zero_grad()
             return self.loss, self.infos

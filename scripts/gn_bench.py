@@ -11,13 +11,19 @@ shapes = [(6, 1024, 14), (6, 512, 4), (12, 512, 6), (12, 128, 4), (24, 128, 5)] 
 
 
 def timeit(fn, n=30):
+    """n launches captured into one hipGraph and replayed (the Python wrapper costs more than these kernels)"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n

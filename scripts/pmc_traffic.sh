@@ -28,7 +28,7 @@ def family(name):
 res = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = collect(counter)
-    adam = [i for i, r in enumerate(rows) if "adam_ema_kernel" in r["Kernel_Name"]]
+    adam = [i for i, r in enumerate(rows) if "mse_fwd_kernel" in r["Kernel_Name"]]   # one per optimizer step
     lo, hi = adam[-3] + 1, adam[-1] + 1            # the last two optimizer steps (steady state, after autotuning)
     for r in rows[lo:hi]:
         f = family(r["Kernel_Name"])
