@@ -213,8 +213,8 @@ class FlatAdamEMA:
     def _launch_bucket(self, b):
         if not self.dp:
             # single process: nothing to reduce; the bucket's optimizer slice goes onto the "wgrad" branch
-            if self._announced is None or not self.use_hip:
-                return
+            if self._announced is None or not self.use_hip or ops.TIMER is not None:
+                return                        # (per-launch event timing: keep the timed kernels alone on the GPU)
             cur = torch.cuda.current_stream()
             tgt = ops.aux_stream(cur.device, "wgrad") if ops.WGRAD_SIDE_STREAM else cur
             if tgt.cuda_stream != cur.cuda_stream:
@@ -247,7 +247,7 @@ class FlatAdamEMA:
             ops.join_aux_streams(self._comm_stream)  # members of the bucket may have been produced on a side branch
             with torch.cuda.stream(self._comm_stream):
                 b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                if self._announced is not None and self.use_hip and self.overlap:
+                if self._announced is not None and self.use_hip and self.overlap and ops.TIMER is None:
                     b["work"].wait()          # orders the communication stream behind the collective (no host wait)
                     self._adam_slice(b["lo"], b["hi"], *self._announced, self._comm_stream)
                     b["work"], b["opt"] = "done", True
