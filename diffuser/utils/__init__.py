@@ -12,3 +12,4 @@ from madiff_amd.host import (  # noqa: F401
     to_np,
     to_torch,
 )
+from madiff_amd.training import EMA, Trainer, cycle  # noqa: F401,E402

@@ -428,32 +428,48 @@ class GraphedTrainStep:
     replayed backward pass, then the fused Adam/EMA launch follows eagerly.
     Call after at least one eager train_step (buffers materialised, GEMM variants tuned)."""
 
-    def __init__(self, diffusion, opt: FlatAdamEMA, example_batch: dict, draws: Optional[dict] = None):
-        """draws = {"t", "noise", "dropout_mask"} fixes the random draws of every replay (parity tests)."""
+    def __init__(self, diffusion, opt: FlatAdamEMA, example_batch, draws=None, warm_do_ema: int = 0):
+        """example_batch: one batch dict, or a list of them = the micro-batches of one optimizer step (the reference's
+        gradient_accumulate_every, training.py:147-152; each loss is scaled by 1/len before backward).
+        draws = {"t", "noise", "dropout_mask"} (or one such dict per micro-batch) fixes the random draws of every
+        replay (parity tests).  The constructor performs ONE real optimizer step on example_batch, eagerly on the
+        capture stream (allocator / autograd warm-up), with EMA mode warm_do_ema; its (loss, infos) is `self.first`."""
         assert opt.flat_p is not None and opt.use_hip
+        self._warm_ema = int(warm_do_ema)
         self.dp = opt.dp
-        self.draws = None if draws is None else {k: v.clone() for k, v in draws.items()}
+        self.single = isinstance(example_batch, dict)
+        examples = [example_batch] if self.single else list(example_batch)
+        n = len(examples)
+        if draws is not None:
+            draws = [draws] * n if isinstance(draws, dict) else list(draws)
+            assert len(draws) == n
+        self.draws = None if draws is None else [{k: v.clone() for k, v in d.items()} for d in draws]
         self.diffusion, self.opt = diffusion, opt
         clone = lambda v: {k: clone(u) for k, u in v.items()} if isinstance(v, dict) else v.clone()  # noqa: E731
-        self.batch = clone(example_batch)
+        self.batches = [clone(b) for b in examples]
+        self.batch = self.batches[0]
         dev = opt.flat_p.device
         net = diffusion.model
         self.mask_dist = net.net.mask_dist if getattr(net, "returns_condition", False) else None
-        B = example_batch["x"].shape[0]
-        self.mask = torch.ones(B, net.n_agents, 1, device=dev)
+        B = examples[0]["x"].shape[0]
+        assert all(b["x"].shape[0] == B for b in examples)
+        self.masks = torch.ones(n, B, net.n_agents, 1, device=dev)
+        self.mask = self.masks[0]
         if self.draws is not None:
             self.mask_dist = None
-            self.mask.copy_(self.draws["dropout_mask"].reshape(self.mask.shape))
-        # host staging for the per-step mask: a ring of pinned buffers, each guarded by an event, because the host runs
+            for i, d in enumerate(self.draws):
+                self.masks[i].copy_(d["dropout_mask"].reshape(self.masks[i].shape))
+        # host staging for the per-step masks: a ring of pinned buffers, each guarded by an event, because the host runs
         # several replays ahead of the GPU and must not overwrite a buffer whose async copy has not executed yet
-        self._ring = [(torch.ones(B, net.n_agents, 1).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+        self._ring = [(torch.ones(n, B, net.n_agents, 1).pin_memory(), torch.cuda.Event()) for _ in range(4)]
         self._ring_pos = 0
         self.state = torch.tensor([opt.step_count, 0], dtype=torch.int32, device=dev)   # {completed steps, EMA mode}
         assert ops.TIMER is None, "per-launch event timing cannot be captured"
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
+        self._refresh_masks()
         with torch.cuda.stream(side):          # one more eager step on the capture stream (allocator / autograd warm-up)
-            self._body()
+            self.first = self._body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -470,12 +486,17 @@ class GraphedTrainStep:
         self.state.copy_(torch.tensor([opt.step_count, 0], dtype=torch.int32))
 
     def _body(self, captured: bool = False):
-        extra = {} if self.draws is None else {"t": self.draws["t"], "noise": self.draws["noise"]}
-        self.opt.set_sync(True)
-        if not captured:
-            self.opt.begin_step(0)
-        loss, infos = self.diffusion.loss(**self.batch, dropout_mask=self.mask, **extra)
-        loss.backward()
+        n = len(self.batches)
+        for i, batch in enumerate(self.batches):
+            extra = {} if self.draws is None else {"t": self.draws[i]["t"], "noise": self.draws[i]["noise"]}
+            self.opt.set_sync(i == n - 1)          # bucket hooks (all-reduce / optimizer slices): last micro-batch only
+            if i == n - 1 and not captured:
+                self.opt.begin_step(self._warm_ema)
+            kw = dict(batch)
+            kw.setdefault("dropout_mask", self.masks[i])     # a batch may carry its own explicit draws (parity tests)
+            kw.update(extra)
+            loss, infos = self.diffusion.loss(**kw)
+            (loss if n == 1 else loss / n).backward()
         if captured and self.dp:
             # data parallel: the graph ends with backward; all-reduce and Adam are issued after each replay
             ops.join_aux_streams()
@@ -484,9 +505,22 @@ class GraphedTrainStep:
             self.opt.step_count -= 1
             self.opt.zero_grad()
         else:
-            self.opt.step(0)
+            self.opt.step(self._warm_ema)
             self.opt.zero_grad()
         return loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in infos.items()}
+
+    def _refresh_masks(self):
+        """New classifier-free-guidance dropout masks for the coming step: one draw of shape (B, A, 1) per micro-batch,
+        in order, on the CPU generator, as the reference's forward makes them (ma_temporal.py:346-351)."""
+        if self.mask_dist is None:
+            return
+        host, ev = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        ev.synchronize()
+        for i in range(host.shape[0]):
+            host[i].copy_(self.mask_dist.sample(sample_shape=tuple(host.shape[1:3]) + (1,)).reshape(host.shape[1:]))
+        self.masks.copy_(host, non_blocking=True)
+        ev.record()
 
     def _copy_in(self, dst, src):
         if isinstance(dst, dict):
@@ -495,17 +529,15 @@ class GraphedTrainStep:
         elif dst.data_ptr() != src.data_ptr():
             dst.copy_(src, non_blocking=True)
 
-    def step(self, batch: Optional[dict] = None, do_ema: int = 0):
-        """Replays the captured step on `batch` (None: the batch already in the static buffers)."""
+    def step(self, batch=None, do_ema: int = 0):
+        """Replays the captured step on `batch` (a dict, or the list of micro-batches; None: what the static buffers
+        already hold)."""
         if batch is not None:
-            self._copy_in(self.batch, batch)
-        if self.mask_dist is not None:
-            host, ev = self._ring[self._ring_pos]
-            self._ring_pos = (self._ring_pos + 1) % len(self._ring)
-            ev.synchronize()
-            host.copy_(self.mask_dist.sample(sample_shape=tuple(host.shape[:2]) + (1,)).reshape(host.shape))
-            self.mask.copy_(host, non_blocking=True)
-            ev.record()
+            given = [batch] if isinstance(batch, dict) else list(batch)
+            assert len(given) == len(self.batches)
+            for dst, src in zip(self.batches, given):
+                self._copy_in(dst, src)
+        self._refresh_masks()
         if self.opt.ema_module is None:
             do_ema = 0
         if self.dp:
