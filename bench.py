@@ -238,17 +238,50 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    # per-launch HIP-event timing of the dominant kernels (roofline): the same K steps issued eagerly with an event pair
-    # around every GEMM launch on the launch stream (events cannot be recorded inside a replayed graph)
-    timer = ops.KernelTimer() if rank == 0 else None
-    ops.TIMER = timer
-    barrier()
-    e0 = time.perf_counter()
-    for i in range(args.steps):
-        train_step(dif, opt, [batch], do_ema=1 if (i % 10 == 9) else 0)
-    barrier()
-    dt_eager = time.perf_counter() - e0
-    ops.TIMER = None
+    # per-launch HIP-event timing of the GEMM kernels (roofline).  Graph path: a second capture of the same step with a
+    # timing event-record node before and after every GEMM launch (on the launch's own stream), replayed K times; the
+    # pairs are read after each replay.  So the durations are those of the real step (graph-paced launches, the step's
+    # own concurrency between branches).  Eager path / fallback: the same K steps issued eagerly with a torch event
+    # pair around every GEMM launch.
+    summ, timed_on, dt_inst = None, "", 0.0
+    if graphed is not None:
+        try:
+            gt = ops.GraphKernelTimer()
+            ops.GRAPH_TIMER = gt
+            try:
+                graphed_t = GraphedTrainStep(dif, opt, batch)
+            finally:
+                ops.GRAPH_TIMER = None
+            barrier()
+            e0 = time.perf_counter()
+            for i in range(args.steps):
+                graphed_t.step(batch, do_ema=1 if (i % 10 == 9) else 0)
+                gt.collect()
+            barrier()
+            dt_inst = time.perf_counter() - e0
+            summ = gt.summary()
+            gt.close()
+            timed_on = (f"a second captured graph of the same step with a timing event-record node before and after every GEMM "
+                        f"launch, replayed {args.steps} times right after the timed region "
+                        f"({1e3 * dt_inst / args.steps:.2f} ms/step incl. reading {len(gt.totals)} kernel families' event pairs)")
+            del graphed_t
+        except Exception as e:                       # noqa: BLE001
+            print(f"[rank {rank}] in-graph kernel timing failed ({e!r}); timing an eager pass instead", flush=True)
+            ops.GRAPH_TIMER = None
+            summ = None
+    if summ is None:
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+        barrier()
+        e0 = time.perf_counter()
+        for i in range(args.steps):
+            train_step(dif, opt, [batch], do_ema=1 if (i % 10 == 9) else 0)
+        barrier()
+        dt_inst = time.perf_counter() - e0
+        ops.TIMER = None
+        summ = timer.summary()
+        timed_on = ("an instrumented eager pass of the same K steps right after the timed region "
+                    f"({1e3 * dt_inst / args.steps:.2f} ms/step with the event pairs)")
     train_sps = BATCH * world * args.steps / dt
 
     # ---- sampling: every rank samples its own shard of episodes with the EMA weights; no collective in the loop
@@ -277,14 +310,13 @@ def main():
                   "finite": bool(torch.isfinite(xs).all().item())}
 
     if rank == 0:
-        summ = timer.summary()
         dom = max((k for k in summ if "gemm" in k or "conv_taps" in k), key=lambda k: summ[k]["ms"])   # dominant kernel
         d = summ[dom]
         traffic = load_traffic(dom, d["launches"] / args.steps)
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         kernels = {k: {"launches_per_step": v["launches"] / args.steps, "avg_us": 1e3 * v["ms"] / v["launches"],
                        "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
-                       "share_of_step": v["ms"] / (dt_eager * 1e3)} for k, v in summ.items()}
+                       "share_of_step": v["ms"] / (dt * 1e3)} for k, v in summ.items()}
         fwd_flops_step = FWD_GF_PER_SAMPLE * 1e9 * BATCH
         out = {
             "metric": "denoiser train samples/sec", "value": train_sps, "unit": "samples/s", "n_gpus": world,
@@ -302,8 +334,7 @@ def main():
                          "traffic": traffic, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                          "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                          "launches_per_step": d["launches"] / args.steps,
-                         "timed_on": "an instrumented eager pass of the same K steps right after the timed region "
-                                     f"({1e3 * dt_eager / args.steps:.2f} ms/step with the event pairs)"},
+                         "timed_on": timed_on},
             "kernels": kernels,
             "model_tflops_per_gpu": 3 * fwd_flops_step * args.steps / dt / 1e12,
             "sample": sample,

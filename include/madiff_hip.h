@@ -47,6 +47,11 @@ int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, int ldx2, in
  * backward pass.  Host-side helpers only: they launch nothing. */
 int madiff_event_create(void** event_out);
 int madiff_event_destroy(void* event);
+/* Timing-enabled events for per-launch kernel durations inside a replayed graph (bench.py's roofline object): record one
+ * before and one after a launch with madiff_event_record_external while capturing, read the pair after each replay.
+ * No counterpart in the reference. */
+int madiff_event_create_timed(void** event_out);
+int madiff_event_elapsed_ms(void* start, void* stop, float* ms);
 int madiff_event_record_external(void* event, madiff_stream_t stream);
 int madiff_stream_wait_event(madiff_stream_t stream, void* event);
 

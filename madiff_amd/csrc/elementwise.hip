@@ -532,6 +532,20 @@ extern "C" int madiff_event_create(void** event_out) {
   *event_out = (void*)e;
   return 0;
 }
+// Timing-enabled twin (per-launch kernel durations INSIDE a replayed graph: an event-record node before and after the
+// launch, hipEventElapsedTime after the replay has finished).
+extern "C" int madiff_event_create_timed(void** event_out) {
+  if (!event_out) return -1;
+  hipEvent_t e;
+  hipError_t rc = hipEventCreateWithFlags(&e, hipEventDefault);
+  if (rc != hipSuccess) return (int)rc;
+  *event_out = (void*)e;
+  return 0;
+}
+extern "C" int madiff_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!start || !stop || !ms) return -1;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
 extern "C" int madiff_event_destroy(void* event) { return event ? (int)hipEventDestroy((hipEvent_t)event) : 0; }
 // On a capturing stream this adds an event-record NODE to the graph (executed at every replay); on an ordinary stream it
 // is a plain hipEventRecord.

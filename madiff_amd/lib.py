@@ -22,6 +22,8 @@ _SIGS = {
                         _vp, _i, _i, _i, _i, _i, _vp],
     "madiff_event_create": [_vp],
     "madiff_event_destroy": [_vp],
+    "madiff_event_create_timed": [_vp],
+    "madiff_event_elapsed_ms": [_vp, _vp, _vp],
     "madiff_event_record_external": [_vp, _vp],
     "madiff_stream_wait_event": [_vp, _vp],
     "madiff_conv_gn_mish_fwd": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i,

@@ -238,6 +238,7 @@ class Trainer(object):
             if self.eval_freq > 0 and self.step % self.eval_freq == 0:
                 self.evaluate()
             if self.step % self.log_freq == 0 and self.rank == 0:
+                infos = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in infos.items()}
                 infos_str = " | ".join([f"{key}: {float(val):8.4f}" for key, val in infos.items()])
                 logger.print(f"{self.step}: {float(loss):8.4f} | {infos_str} | t: {time.time() - t0:8.4f}")
                 metrics = {k: float(v.detach().item()) if torch.is_tensor(v) else float(v) for k, v in infos.items()}
