@@ -14,6 +14,7 @@ Differences that are additions, not changes of behaviour:
 from __future__ import annotations
 
 import os
+import weakref
 
 from typing import Dict, Optional
 
@@ -68,6 +69,8 @@ class InvDynMLP(nn.Sequential):
 
 
 INV_SIDE_STREAM = os.environ.get("MADIFF_INV_SIDE_STREAM", "1") != "0"
+# GaussianDiffusion -> its captured denoising step (kept outside the module: deepcopy / pickling of the module stay plain)
+_SAMPLE_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
 class WeightedStateL2(nn.Module):
@@ -217,18 +220,42 @@ class GaussianDiffusion(nn.Module):
         if use_graph is None:
             use_graph = not return_diffusion
 
-        x = (0.5 * torch.randn(shape, device=device)) if x_init is None else x_init.to(device, torch.float32).clone()
         needs_z = not self.use_ddim_sample
-        cond_x = cond["x"].to(device, torch.float32).contiguous()
-        mask = cond["masks"].to(device=device, dtype=torch.uint8).contiguous()
-        st = {"x": x.contiguous(), "cond_x": cond_x, "mask": mask, "coef": tb["coef"], "tsteps": tb["timesteps"],
-              "state": torch.zeros(1, dtype=torch.int32, device=device),
-              "ts": torch.zeros(batch_size, dtype=torch.int64, device=device),
-              "z": torch.empty(shape, dtype=torch.float32, device=device) if needs_z else None}
-        ops.inpaint_(st["x"], cond_x, mask)                       # step 1 of the first iteration (diffusion.py:251)
-        chain = [st["x"].clone()] if return_diffusion else None
+        x0 = (0.5 * torch.randn(shape, device=device)) if x_init is None else x_init.to(device, torch.float32)
         if returns is not None:
             returns = returns.to(device, torch.float32).contiguous()
+
+        # A captured denoising step is kept across calls (the evaluator samples once per environment step,
+        # evaluator.py:272-277): the graph reads persistent buffers, so a later call with the same shapes and unchanged
+        # weights only copies its inputs in and replays.  One entry is kept (its activations are the memory cost).
+        key = (shape, str(device), id(sched), n_steps, returns is not None, None if env_ts is None else tuple(env_ts.shape),
+               ops._PRECISION, ops._EPOCH, sum(p_._version for p_ in self.model.parameters()), self.condition_guidance_w)
+        ent = _SAMPLE_CACHE.get(self)
+        if not (use_graph and ent is not None and ent["key"] == key):
+            ent = None
+        if ent is not None:
+            st, returns_s, env_ts_s, graph = ent["st"], ent["returns"], ent["env_ts"], ent["graph"]
+            st["x"].copy_(x0)
+            st["cond_x"].copy_(cond["x"])
+            st["mask"].copy_(cond["masks"])
+            st["state"].zero_()
+            if returns_s is not None:
+                returns_s.copy_(returns)
+            if env_ts_s is not None:
+                env_ts_s.copy_(env_ts)
+        else:
+            _SAMPLE_CACHE.pop(self, None)
+            st = {"x": x0.clone().contiguous(), "cond_x": cond["x"].to(device, torch.float32).contiguous().clone(),
+                  "mask": cond["masks"].to(device=device, dtype=torch.uint8).contiguous().clone(),
+                  "coef": tb["coef"], "tsteps": tb["timesteps"],
+                  "state": torch.zeros(1, dtype=torch.int32, device=device),
+                  "ts": torch.zeros(batch_size, dtype=torch.int64, device=device),
+                  "z": torch.empty(shape, dtype=torch.float32, device=device) if needs_z else None}
+            returns_s = None if returns is None else returns.clone()
+            env_ts_s = None if env_ts is None else env_ts.to(device).contiguous().clone()
+            graph = None
+        ops.inpaint_(st["x"], st["cond_x"], st["mask"])           # step 1 of the first iteration (diffusion.py:251)
+        chain = [st["x"].clone()] if return_diffusion else None
 
         def draw(i):
             if not needs_z:
@@ -239,7 +266,6 @@ class GaussianDiffusion(nn.Module):
             else:
                 st["z"].normal_()
 
-        graph = None
         for i in range(n_steps):
             draw(i)
             if graph is not None:
@@ -251,13 +277,15 @@ class GaussianDiffusion(nn.Module):
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with ops.graph_capture(graph):
-                    self._denoise_step(st, returns, env_ts, batch_size, t_len)
+                    self._denoise_step(st, returns_s, env_ts_s, batch_size, t_len)
                 graph.replay()
+                _SAMPLE_CACHE[self] = {"key": key, "st": st, "returns": returns_s, "env_ts": env_ts_s, "graph": graph}
             else:
-                self._denoise_step(st, returns, env_ts, batch_size, t_len)
+                self._denoise_step(st, returns_s, env_ts_s, batch_size, t_len)
             if return_diffusion:
                 chain.append(st["x"].clone())
-        x = st["x"]        # the posterior kernel already enforced the final conditioning (diffusion.py:268)
+        x = st["x"].clone() if graph is not None else st["x"]     # (the persistent buffer is reused by the next call)
+        # the posterior kernel already enforced the final conditioning (diffusion.py:268)
         if return_diffusion:
             return x, torch.stack(chain, dim=1)
         return x

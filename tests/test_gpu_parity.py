@@ -244,6 +244,47 @@ def test_bf16_sampling_close_to_oracle(golden):
     assert float(np.abs(x.cpu().numpy() - g[tag + ".x"]).mean()) < 1e-2
 
 
+def test_sampler_graph_is_reused_across_calls(golden, prec):
+    """The evaluator samples once per environment step (evaluator.py:272-277): the captured denoising step is kept
+    between calls.  A second call with OTHER inputs of the same shape replays the kept graph and must equal an eager run
+    on those inputs (fp32 build: and the reference trajectory of the golden file); changing a weight drops the graph."""
+    import copy
+    from madiff_amd import ops
+    from madiff_amd import diffusion as D
+    g = golden("g6_sample")
+    dev = torch.device("cuda:0")
+    tag, K = "smac_k20", 20
+    A, Tt, Fd, hh = SHAPES["smac"]
+    ops.set_precision(prec)
+    try:
+        dif, _ = build("smac", 16, K)
+        dif2 = copy.deepcopy(dif)                      # (a module holding a captured graph must stay deep-copyable)
+        shape = (2, Tt, A, Fd)
+        x_init = 0.5 * T(O.closed_form_normal(f"{tag}.0", shape), dev)
+        z = torch.stack([T(O.closed_form_normal(f"{tag}.{i}", shape)) for i in range(1, K)]).to(dev)
+        cond = {"x": T(g[tag + ".cond_x"], dev), "masks": T(g[tag + ".cond_masks"], dev)}
+        ret = T(g[tag + ".returns"], dev)
+        other = {"x": cond["x"].flip(0).contiguous() * 0.5, "masks": cond["masks"].flip(0).contiguous()}
+        x_other = dif.conditional_sample(other, returns=ret.flip(0).contiguous(), verbose=False, x_init=x_init * 0.9,
+                                         step_noise=z.flip(1).contiguous())                 # captures
+        ent = D._SAMPLE_CACHE.get(dif)
+        assert ent is not None
+        x = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, step_noise=z)     # replays
+        assert D._SAMPLE_CACHE.get(dif) is ent and ent["graph"] is not None
+        x_eager = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, step_noise=z, use_graph=False)
+        assert rel_err(x.cpu(), x_eager.cpu()) < (1e-6 if prec == "fp32" else 1e-2)
+        assert not torch.equal(x, x_other)
+        if prec == "fp32":
+            assert rel_err(x.cpu(), g[tag + ".x"]) < 1e-3
+        assert D._SAMPLE_CACHE.get(dif2) is None
+        with torch.no_grad():                          # a weight write (version bump) must invalidate the kept graph
+            next(dif.model.parameters()).mul_(1.0)
+        dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, step_noise=z)
+        assert D._SAMPLE_CACHE.get(dif) is not ent
+    finally:
+        ops.set_precision("bf16")
+
+
 def test_full_size_properties():
     """BASELINE configs[1] size (B=256, A=4, T=24, F=16, dim 128): size-independent properties instead of an
     oracle run: permutation equivariance over the batch, exact inpainting, finite loss and gradients, and the
