@@ -345,10 +345,33 @@ def gen_sample(R):
     save("g6_sample", **out)
 
 
+def gen_masks():
+    """g7: conditioning masks of the reference's own MultiAgentMaskGenerator (utils/mask_generator.py:11-59, a
+    numpy/einops-only file, loaded directly) for the shapes and agent-visibility patterns the evaluator builds
+    (evaluator.py:56-72 decentralized: one visible agent; :117-120 centralized: all visible)."""
+    spec = importlib.util.spec_from_file_location("ref_mask_generator", REF + "/utils/mask_generator.py")
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    out = {}
+    for name, (A, T, F, hh) in {"spread": (3, 24, 18, 0), "ant": (4, 28, 54, 18), "smac": (8, 24, 88, 20)}.items():
+        gen = mg.MultiAgentMaskGenerator(action_dim=5, observation_dim=F, history_horizon=hh, action_visible=False)
+        out[f"{name}.all"] = gen((2, T, A, F), np.ones(A))
+        for a_idx in (0, A - 1):
+            am = np.zeros(A)
+            am[a_idx] = 1.0
+            out[f"{name}.only{a_idx}"] = gen((2, T, A, F), am)
+    save("g7_masks", **{k: np.packbits(v.astype(np.uint8), axis=None) for k, v in out.items()},
+         **{k + ".shape": np.asarray(v.shape) for k, v in out.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "masks":
+        gen_masks()
+        return
     torch.manual_seed(1234)
     torch.set_num_threads(8)
     R = load_reference()
+    gen_masks()
     gen_modules(R)
     gen_denoiser(R, 16, ["spread", "tag", "ant", "smac"], "g2_denoiser_w16", True)
     gen_denoiser(R, 128, ["spread"], "g3_denoiser_w128", False)
