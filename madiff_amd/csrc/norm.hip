@@ -594,9 +594,6 @@ static int gn_bwd_rb(int dtype, const void* y, int ldy, const void* dout, int ld
   if (nb > (N + 3) / 4) nb = (N + 3) / 4;
   if (nb < 1) nb = 1;
   dim3 grid(ranges, nb);
-  static int noat = -1;
-  if (noat < 0) { const char* e = getenv("MADIFF_GN_NOATOMIC"); noat = e ? atoi(e) : 0; }
-  if (noat) dgamma = dbeta = dbias = nullptr;
 #define GN_BWD_CALL(V)                                                                                                  \
   if (dtype == MADIFF_BF16)                                                                                             \
     hipLaunchKernelGGL((gn_mish_bwd_rb_kernel<bf16_t, V>), grid, dim3(256), 0, stream, (const bf16_t*)y, ldy,           \

@@ -2,6 +2,7 @@
 # rocprofv3 kernel trace of the bench's training region (the command the roofline object is measured on):
 #   python3 bench.py --steps 10 --warmup 2 --no-sample --no-cpu
 # usage: scripts/prof.sh <tag> [extra bench args]; the caller copies the stats CSV into profiles/.
+
 cd /tmp && export TMPDIR=/tmp
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG

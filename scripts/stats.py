@@ -1,5 +1,5 @@
-import csv, sys, glob
-f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
+import csv, os, sys, glob
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 25

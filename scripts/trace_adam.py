@@ -1,7 +1,7 @@
 """debug: where the adam_ema_kernel slices run inside a step (from a rocprofv3 kernel trace)"""
-import csv, glob, sys
+import csv, glob, os, sys
 d = sys.argv[1]
-f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 pk = [i for i, r in enumerate(rows) if "mse_fwd_kernel" in r["Kernel_Name"]]

@@ -2,13 +2,13 @@
 mse_fwd_kernel dispatches, one per step), and prints, per (kernel, grid) bucket, launches per step, average duration and share, plus
 GPU busy time vs wall time per step (the difference is launch gaps / host-bound time).
 usage: python scripts/trace_steps.py <dir with *_kernel_trace.csv> [nsteps=5] [topN=40] [skip_last_steps=0]"""
-import csv, glob, sys, collections, re
+import csv, glob, os, sys, collections, re
 
 d = sys.argv[1]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # ignore the last `skip` steps (bench.py's instrumented eager pass)
-f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # one mse_fwd_kernel per optimizer step (the Adam/EMA pass is issued in per-bucket slices all over backward)
