@@ -251,7 +251,9 @@ __device__ __forceinline__ void att2_scores(const T* __restrict__ qkv, int ldq, 
   __syncthreads();
 }
 
-template <typename T>
+// AM: compile-time bound on the number of agents (4 or 8): the per-agent register arrays are sized by it, and the
+// backward kernel needs 219 VGPRs at AM = 8 (two workgroups per CU) against half of that at AM = 4
+template <typename T, int AM>
 __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(const T* __restrict__ qkv, int ldq, const T* __restrict__ x, int ldx,
                                                           T* __restrict__ out, int ldo, const float* __restrict__ gamma_p,
                                                           int B, int A, int Tn, int H, int Cq, int C, float scale, int residual) {
@@ -268,18 +270,18 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(const T* __restrict__ 
   for (int i = threadIdx.x; i < nv; i += 256) {
     int cv = i % vpr, t = i / vpr;
     const int c = h * dv + cv * E;
-    float v[ATT2_AMAX][E];
+    float v[AM][E];
 #pragma unroll
-    for (int a2 = 0; a2 < ATT2_AMAX; a2++)
+    for (int a2 = 0; a2 < AM; a2++)
       if (a2 < A) ald<T>(qkv + ((size_t)(b * A + a2) * Tn + t) * ldq + 2 * Cq + c, v[a2]);
 #pragma unroll
-    for (int a1 = 0; a1 < ATT2_AMAX; a1++) {
+    for (int a1 = 0; a1 < AM; a1++) {
       if (a1 >= A) break;
       float o[E];
 #pragma unroll
       for (int e = 0; e < E; e++) o[e] = 0.f;
 #pragma unroll
-      for (int a2 = 0; a2 < ATT2_AMAX; a2++)
+      for (int a2 = 0; a2 < AM; a2++)
         if (a2 < A) {
           float p = Ps[a1 * A + a2];
 #pragma unroll
@@ -297,14 +299,14 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(const T* __restrict__ 
   }
 }
 
-template <typename T>
+template <typename T, int AM>
 __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(const T* __restrict__ qkv, int ldq, const T* __restrict__ dout, int ldd,
                                                           T* __restrict__ dqkv, int ldg, const float* __restrict__ gamma_p,
                                                           float* __restrict__ dgamma, int B, int A, int Tn, int H, int Cq, int C,
                                                           float scale, int residual) {
   constexpr int E = AVec<T>::E;
   extern __shared__ float sm[];
-  __shared__ float Dw[4][ATT2_AMAX * ATT2_AMAX];
+  __shared__ float Dw[4][AM * AM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dqk = Cq / H, dv = C / H, L = Tn * dqk;
   float* qs = sm;
@@ -315,27 +317,27 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(const T* __restrict__ 
   const float gamma = residual ? gamma_p[0] : 1.f;
   att2_scores<T>(qkv, ldq, b, h, A, Tn, dqk, Cq, scale, qs, ks, Ps);
   // pass over the value slice: raw dP[a1][a2] = sum dO[a1].v[a2] (per-thread partials) and dv = gamma * P^T dO
-  float dp[ATT2_AMAX][ATT2_AMAX];
+  float dp[AM][AM];
 #pragma unroll
-  for (int i = 0; i < ATT2_AMAX; i++)
+  for (int i = 0; i < AM; i++)
 #pragma unroll
-    for (int j = 0; j < ATT2_AMAX; j++) dp[i][j] = 0.f;
+    for (int j = 0; j < AM; j++) dp[i][j] = 0.f;
   const int vprv = dv / E, nvv = Tn * vprv;
   for (int i = threadIdx.x; i < nvv; i += 256) {
     int cv = i % vprv, t = i / vprv;
     const int c = h * dv + cv * E;
-    float v[ATT2_AMAX][E], g[ATT2_AMAX][E];
+    float v[AM][E], g[AM][E];
 #pragma unroll
-    for (int a = 0; a < ATT2_AMAX; a++)
+    for (int a = 0; a < AM; a++)
       if (a < A) {
         size_t row = (size_t)(b * A + a) * Tn + t;
         ald<T>(qkv + row * ldq + 2 * Cq + c, v[a]);
         ald<T>(dout + row * ldd + c, g[a]);
       }
 #pragma unroll
-    for (int a1 = 0; a1 < ATT2_AMAX; a1++)
+    for (int a1 = 0; a1 < AM; a1++)
 #pragma unroll
-      for (int a2 = 0; a2 < ATT2_AMAX; a2++)
+      for (int a2 = 0; a2 < AM; a2++)
         if (a1 < A && a2 < A) {
           float s = 0.f;
 #pragma unroll
@@ -343,13 +345,13 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(const T* __restrict__ 
           dp[a1][a2] += s;
         }
 #pragma unroll
-    for (int a2 = 0; a2 < ATT2_AMAX; a2++) {
+    for (int a2 = 0; a2 < AM; a2++) {
       if (a2 >= A) break;
       float o[E];
 #pragma unroll
       for (int e = 0; e < E; e++) o[e] = 0.f;
 #pragma unroll
-      for (int a1 = 0; a1 < ATT2_AMAX; a1++)
+      for (int a1 = 0; a1 < AM; a1++)
         if (a1 < A) {
           float p = Ps[a1 * A + a2];
 #pragma unroll
@@ -361,9 +363,9 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(const T* __restrict__ 
     }
   }
 #pragma unroll
-  for (int a1 = 0; a1 < ATT2_AMAX; a1++)
+  for (int a1 = 0; a1 < AM; a1++)
 #pragma unroll
-    for (int a2 = 0; a2 < ATT2_AMAX; a2++)
+    for (int a2 = 0; a2 < AM; a2++)
       if (a1 < A && a2 < A) {
         float s = wave_sum(dp[a1][a2]);
         if (lane == 0) Dw[wave][a1 * A + a2] = s;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(const T* __restrict__ 
   __syncthreads();
   if (threadIdx.x < A) {       // row a1: dgamma partial and softmax backward -> dS (already times scale)
     const int a1 = threadIdx.x;
-    float d[ATT2_AMAX], dot = 0.f;
+    float d[AM], dot = 0.f;
     for (int j = 0; j < A; j++) {
       d[j] = Dw[0][a1 * A + j] + Dw[1][a1 * A + j] + Dw[2][a1 * A + j] + Dw[3][a1 * A + j];
       dot += Ps[a1 * A + j] * d[j];
@@ -417,12 +419,12 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_attn_fwd_v2(int dtyp
     void* out, int ldo, const float* gamma, int B, int A, int T, int H, int Cq, int C, float scale, int residual, hipStream_t stream) {
   if (!att2_ok(dtype, A, T, H, Cq, C, ldq, ldx, ldo)) return 1;
   size_t sh = att2_lds(A, T, H, Cq);
-  if (dtype == MADIFF_BF16)
-    hipLaunchKernelGGL((attn_fwd_v2_kernel<bf16_t>), dim3(B * H), dim3(256), sh, stream, (const bf16_t*)qkv, ldq, (const bf16_t*)x, ldx,
-                       (bf16_t*)out, ldo, gamma, B, A, T, H, Cq, C, scale, residual);
-  else
-    hipLaunchKernelGGL((attn_fwd_v2_kernel<float>), dim3(B * H), dim3(256), sh, stream, (const float*)qkv, ldq, (const float*)x, ldx,
-                       (float*)out, ldo, gamma, B, A, T, H, Cq, C, scale, residual);
+#define ATT2_FWD(T_, AM_)                                                                                                  \
+  hipLaunchKernelGGL((attn_fwd_v2_kernel<T_, AM_>), dim3(B * H), dim3(256), sh, stream, (const T_*)qkv, ldq, (const T_*)x, ldx, \
+                     (T_*)out, ldo, gamma, B, A, T, H, Cq, C, scale, residual)
+  if (dtype == MADIFF_BF16) { if (A <= 4) ATT2_FWD(bf16_t, 4); else ATT2_FWD(bf16_t, 8); }
+  else { if (A <= 4) ATT2_FWD(float, 4); else ATT2_FWD(float, 8); }
+#undef ATT2_FWD
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -431,11 +433,11 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_attn_bwd_v2(int dtyp
     hipStream_t stream) {
   if (!att2_ok(dtype, A, T, H, Cq, C, ldq, ldd, ldg)) return 1;
   size_t sh = att2_lds(A, T, H, Cq);
-  if (dtype == MADIFF_BF16)
-    hipLaunchKernelGGL((attn_bwd_v2_kernel<bf16_t>), dim3(B * H), dim3(256), sh, stream, (const bf16_t*)qkv, ldq, (const bf16_t*)dout,
-                       ldd, (bf16_t*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual);
-  else
-    hipLaunchKernelGGL((attn_bwd_v2_kernel<float>), dim3(B * H), dim3(256), sh, stream, (const float*)qkv, ldq, (const float*)dout,
-                       ldd, (float*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual);
+#define ATT2_BWD(T_, AM_)                                                                                                  \
+  hipLaunchKernelGGL((attn_bwd_v2_kernel<T_, AM_>), dim3(B * H), dim3(256), sh, stream, (const T_*)qkv, ldq, (const T_*)dout, \
+                     ldd, (T_*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual)
+  if (dtype == MADIFF_BF16) { if (A <= 4) ATT2_BWD(bf16_t, 4); else ATT2_BWD(bf16_t, 8); }
+  else { if (A <= 4) ATT2_BWD(float, 4); else ATT2_BWD(float, 8); }
+#undef ATT2_BWD
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
