@@ -27,8 +27,12 @@ def set_precision(name: str) -> None:
     global _PRECISION
     assert name in ("bf16", "fp32")
     if name != _PRECISION:
+        global _TUNE
         _PRECISION = name
         _PACK_CACHE.clear()
+        # kernel-variant choices are per build: a (variant, splits) pair tuned for the bf16 kernels names variants the
+        # fp32 build does not have (its launch would be refused and the gradient never written)
+        _TUNE = _TUNE_BY_PRECISION.setdefault(name, {})
 
 
 def get_precision() -> str:
@@ -392,7 +396,8 @@ def _tile_label(tile):
 # ------------------------------------------------------------------------------------------------
 # raw launches
 # ------------------------------------------------------------------------------------------------
-_TUNE: dict = {}
+_TUNE_BY_PRECISION: dict = {_PRECISION: {}}
+_TUNE: dict = _TUNE_BY_PRECISION[_PRECISION]
 _AUTOTUNE = os.environ.get("MADIFF_AUTOTUNE", "1") != "0"
 
 
@@ -515,7 +520,11 @@ def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, acc
         cfg = _TUNE[sig] = best
     if cfg is None:
         cfg = (-1, 0)
-    launch(dW, accumulate, cfg[0], cfg[1])
+    if launch(dW, accumulate, cfg[0], cfg[1]) != 0:
+        # (a remembered variant that does not cover this layer after all: the library's own choice must)
+        if cfg == (-1, 0) or launch(dW, accumulate, -1, 0) != 0:
+            raise RuntimeError("madiff_gemm_wgrad: no kernel variant covers this layer")
+        cfg = _TUNE[sig] = (-1, 0)
     return "gemm_wgrad_taps_bf16_kernel" if (cfg[0] >= 4 and _PRECISION == "bf16") else None
 
 
