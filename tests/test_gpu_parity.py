@@ -285,8 +285,10 @@ def test_sampler_graph_is_reused_across_calls(golden, prec):
         ops.set_precision("bf16")
 
 
-def test_full_size_gradients_agree_between_builds():
-    """BASELINE configs[1] size: the oracle cannot run this size in seconds, so the two builds check each other: same
+@pytest.mark.parametrize("shape", [("tag", 4, 24, 16, 0, 5, 0, 256), ("ant", 4, 28, 54, 18, 2, 0, 64),
+                                   ("smac", 8, 24, 88, 20, 1, 14, 64)], ids=lambda s: s[0])
+def test_full_size_gradients_agree_between_builds(shape):
+    """Full width (dim 128) at BASELINE's shapes: the oracle cannot run this size in seconds, so the two builds check each other: same
     weights, batch and draws, bf16-build gradients against fp32-build gradients, parameter by parameter (relative L2
     < 10 %, cosine > 0.99; measured: worst 3.4 %, 0.9996).  The bf16 pass runs first and autotunes its kernel variants:
     the fp32 pass in the same process must not inherit them (it once did: its weight-gradient launches were refused
@@ -296,14 +298,14 @@ def test_full_size_gradients_agree_between_builds():
     from madiff_amd.host import batch_to_device
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    A, Tt, Fd, B = 4, 24, 16, 256
-    net = DM.SharedConvAttentionDeconv(horizon=Tt, transition_dim=Fd, dim=128, dim_mults=(1, 4, 8), n_agents=A,
-                                       returns_condition=True, condition_dropout=0.25)
-    dif = DM.GaussianDiffusion(net, n_agents=A, horizon=Tt, history_horizon=0, observation_dim=Fd, action_dim=5,
-                               n_timesteps=200, returns_condition=True).to(dev)
+    _, A, Tt, Fd, hh, act, nact, B = shape
+    net = DM.SharedConvAttentionDeconv(horizon=Tt, transition_dim=Fd, dim=128, history_horizon=hh, dim_mults=(1, 4, 8),
+                                       n_agents=A, returns_condition=True, condition_dropout=0.25)
+    dif = DM.GaussianDiffusion(net, n_agents=A, horizon=Tt - hh, history_horizon=hh, observation_dim=Fd, action_dim=act,
+                               discrete_action=nact > 0, num_actions=nact, n_timesteps=200, returns_condition=True).to(dev)
     for a in net.self_attn:
         a.gamma.data.fill_(0.5)
-    batch = batch_to_device(O.synthetic_batch(B, Tt, A, Fd, 5, 0, seed=0), dev)
+    batch = batch_to_device(O.synthetic_batch(B, Tt, A, Fd, act, hh, discrete=nact > 0, num_actions=nact, seed=0), dev)
     g = torch.Generator().manual_seed(3)
     draws = dict(t=torch.randint(0, 200, (B,), generator=g).to(dev), noise=torch.randn(B, Tt, A, Fd, generator=g).to(dev),
                  dropout_mask=(torch.rand(B, A, 1, generator=g) < 0.75).float().to(dev))
