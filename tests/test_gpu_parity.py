@@ -331,6 +331,47 @@ def test_full_size_gradients_agree_between_builds(shape):
         assert rel < 0.1 and cos > 0.99, (k, rel, cos)
 
 
+@pytest.mark.parametrize("shape", [("tag", 4, 24, 16, 0, 5, 0, 64), ("smac", 8, 24, 88, 20, 1, 14, 16)], ids=lambda s: s[0])
+def test_full_size_sampling_agrees_between_builds(shape):
+    """Full width, K = 12 guided steps replayed from the kept graph: the bf16 build against the fp32 build on the same
+    weights, initial draw and step noise (each build's sampler is pinned to the reference at small width / K = 8 full
+    width elsewhere; this covers the bf16 kernels at the sizes the benchmark runs)."""
+    import diffuser.models as DM
+    from madiff_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    _, A, Tt, Fd, hh, act, nact, B = shape
+    K = 12
+    net = DM.SharedConvAttentionDeconv(horizon=Tt, transition_dim=Fd, dim=128, history_horizon=hh, dim_mults=(1, 4, 8),
+                                       n_agents=A, returns_condition=True, condition_dropout=0.25)
+    dif = DM.GaussianDiffusion(net, n_agents=A, horizon=Tt - hh, history_horizon=hh, observation_dim=Fd, action_dim=act,
+                               discrete_action=nact > 0, num_actions=nact, n_timesteps=K, returns_condition=True).to(dev)
+    for a in net.self_attn:
+        a.gamma.data.fill_(0.5)
+    b = O.synthetic_batch(B, Tt, A, Fd, act, hh, discrete=nact > 0, num_actions=nact, seed=0)
+    cond = {k: v.to(dev) for k, v in b["cond"].items()}
+    ret = b["returns"].to(dev)
+    g = torch.Generator().manual_seed(7)
+    x_init = (0.5 * torch.randn(B, Tt, A, Fd, generator=g)).to(dev)
+    z = torch.randn(K - 1, B, Tt, A, Fd, generator=g).to(dev)
+    xs = {}
+    try:
+        for prec in ("bf16", "fp32"):
+            ops.set_precision(prec)
+            for rep in range(2):                          # second call: the kept graph
+                xs[prec] = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, step_noise=z)
+    finally:
+        ops.set_precision("bf16")
+    assert bool(torch.isfinite(xs["bf16"]).all())
+    assert torch.equal(xs["bf16"][cond["masks"]], cond["x"][cond["masks"]])          # inpainting is exact
+    # The first scheduler steps divide by sqrt(abar_t) ~ 1e-3 and clamp to [-1, 1] (a third of the elements sit on the
+    # clamp): an element that lands just inside the clamp amplifies the 1 % difference of one guided epsilon call
+    # (measured: 1.3 %) a thousandfold, so single elements may differ by O(1).  Bound the bulk instead.
+    d = (xs["bf16"] - xs["fp32"]).abs().flatten()
+    assert float(d.mean()) < 1e-2
+    assert float(d.kthvalue(int(0.99 * d.numel())).values) < 0.05
+
+
 def test_full_size_properties():
     """BASELINE configs[1] size (B=256, A=4, T=24, F=16, dim 128): size-independent properties instead of an
     oracle run: permutation equivariance over the batch, exact inpainting, finite loss and gradients, and the
