@@ -1,0 +1,83 @@
+"""Two data-parallel ranks on ONE GPU at full width (bf16 build, tag shape, 64 windows per rank, 32 MB buckets): eager
+steps, then the graph-replayed step with bucket event nodes, all-reduce + optimizer slices behind them (collectives staged
+through gloo as in tests/test_gpu_dp2.py).  Ranks must end bit-identical; the parameter movement must match a
+single-process run on the concatenated batch."""
+import copy, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import torch.multiprocessing as mp
+
+B = 128
+
+
+def setup():
+    import bench
+    from madiff_amd import ops
+    ops.set_precision("bf16")
+    bench.select_workload("tag", B)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    dif = bench.build(dev)
+    batch = bench.synthetic_batch(B, dev, 0)
+    g = torch.Generator().manual_seed(5)
+    draws = dict(t=torch.randint(0, 200, (B,), generator=g).to(dev),
+                 noise=torch.randn(B, bench.T, bench.A, bench.F_OBS, generator=g).to(dev),
+                 dropout_mask=(torch.rand(B, bench.A, 1, generator=g) < 0.75).float().to(dev))
+    return dif, batch, draws
+
+
+def steps(dif, batch, draws):
+    from madiff_amd import ops
+    from madiff_amd.trainer import FlatAdamEMA, GraphedTrainStep, train_step
+    p_init = torch.cat([p.detach().flatten().float().cpu() for p in dif.parameters()])
+    ema = copy.deepcopy(dif)
+    opt = FlatAdamEMA(dif, ema, lr=2e-4, ema_decay=0.995, bucket_mb=32.0)
+    opt.broadcast_parameters(0)
+    for i in range(2):
+        train_step(dif, opt, [{**batch, **draws}], do_ema=1)
+    gs = GraphedTrainStep(dif, opt, batch, draws=draws)
+    for i in range(3):
+        loss, _ = gs.step(batch, do_ema=i % 2)
+    torch.cuda.synchronize()
+    assert opt.step_count == 6
+    ops.SINK = None
+    p_end = torch.cat([p.detach().flatten().float().cpu() for p in dif.parameters()])
+    return p_init, p_end, float(loss), len(opt.buckets), opt.dp
+
+
+def sl(v, s):
+    return {k: sl(u, s) for k, u in v.items()} if isinstance(v, dict) else v[s].contiguous()
+
+
+def run(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import test_gpu_dp2 as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D._host_staged_collectives(dist)
+    dif, batch, draws = setup()
+    half = slice(0, B // 2) if rank == 0 else slice(B // 2, B)
+    p0, p1, loss, nb, dp = steps(dif, sl(batch, half), sl(draws, half))
+    assert dp and nb >= 8
+    out[rank] = (p1, loss)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(run, args=(2, 29755, out), nprocs=2, join=True)
+    (a, la), (b, lb) = out[0], out[1]
+    print("ranks bit-identical:", bool(torch.equal(a, b)), "losses", la, lb, flush=True)
+    dif, batch, draws = setup()
+    p0, p1, loss, nb, dp = steps(dif, batch, draws)
+    assert not dp
+    mv_single, mv_dp = (p1 - p0).double(), (a - p0).double()
+    rel = float((mv_dp - mv_single).norm() / mv_single.norm())
+    cos = float((mv_dp * mv_single).sum() / (mv_dp.norm() * mv_single.norm()))
+    print(f"parameter movement after 6 steps, 2-rank DP vs single process: relative L2 difference {rel:.4f}, cosine {cos:.5f}; "
+          f"|movement| {float(mv_single.norm()):.4f}", flush=True)
+    assert torch.equal(a, b) and cos > 0.98
+    print("OK")
