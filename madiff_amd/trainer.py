@@ -414,7 +414,7 @@ def train_step(diffusion, opt: FlatAdamEMA, batches, do_ema: int = 0):
 
 class GraphedTrainStep:
     """One optimizer step (loss forward, backward, fused Adam/EMA) captured ONCE into a hipGraph and replayed: the
-    ~340 kernel launches of a step then cost one host call, which matters because at batch 256 the GPU finishes a
+    ~300 kernel launches of a step then cost one host call, which matters because at batch 256 the GPU finishes a
     step faster than Python can issue it.  Same arithmetic as train_step: the graph holds exactly the launches an eager
     step makes.  What changes per step lives in static device buffers refreshed before each replay:
       * the batch (copied into the captured input tensors),
