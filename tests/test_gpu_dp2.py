@@ -119,3 +119,41 @@ def test_two_ranks_on_one_gpu_match_single_process():
     finally:
         ops.SINK = None
         ops.set_precision("bf16")
+
+
+def _run_trainer(rank, world, port, out, ckpt_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _host_staged_collectives(dist)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_trainer as TT
+    from diffuser.utils import Trainer
+    from madiff_amd import ops
+    ops.set_precision("fp32")
+    dif, _ = TT._build(torch.device("cuda:0"))
+    data = TT._Items(TT.B * TT.ACC * 2 * 4)
+    tr = Trainer(dif, data, None, ema_decay=0.9, train_batch_size=TT.B, train_lr=1e-3, gradient_accumulate_every=TT.ACC,
+                 step_start_ema=3, update_ema_every=2, log_freq=10 ** 9, sample_freq=0, save_freq=4, eval_freq=0,
+                 bucket=ckpt_dir, train_device="cuda:0", use_graph=True, shuffle=True, seed=3, bucket_mb=0.25)
+    assert tr.world == 2 and tr.optimizer.dp
+    tr.train(6)
+    torch.cuda.synchronize()
+    assert tr.step == 6 and tr._graphed is not None and tr._graphed.dp
+    out[rank] = (tr.optimizer.flat_p.cpu(), tr.optimizer.flat_ema.cpu(), sorted(os.listdir(os.path.join(ckpt_dir, "checkpoint"))))
+    ops.SINK = None
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_trainer_two_ranks_on_one_gpu(tmp_path):
+    """diffuser.utils.Trainer under data parallelism (two ranks on cuda:0, collectives staged through gloo): every rank
+    draws its own DistributedSampler shard, accumulates two micro-batches inside one captured graph, all-reduces per
+    bucket behind the graph's event nodes; the ranks must stay bit-identical and only rank 0 writes checkpoints."""
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    port = 29650 + os.getpid() % 300
+    mp.spawn(_run_trainer, args=(2, port, out, str(tmp_path)), nprocs=2, join=True)
+    (p0, e0, f0), (p1, e1, f1) = out[0], out[1]
+    assert torch.equal(p0, p1) and torch.equal(e0, e1), "ranks diverged"
+    assert bool(torch.isfinite(p0).all()) and f0 == ["state.pt"]
