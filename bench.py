@@ -155,6 +155,72 @@ def cpu_baseline(seconds_budget=30.0):
                       f"{BATCH} windows (same shape), after 1 warm-up step: {dt:.1f} s"}
 
 
+def cpu_baseline_sample(episodes=32, steps=5, seconds_budget=40.0):
+    """BASELINE.md section 3 "Sample": the oracle's guided K-step loop (2 forwards per step, fp32, torch CPU) on this box's
+    host cores, timed over >= `steps` denoising steps on `episodes` episodes of the current sampling shape and
+    EXTRAPOLATED to K steps (a full K=200 run takes tens of minutes on the host)."""
+    from oracle import madiff_oracle as O
+    cores = len(os.sched_getaffinity(0))
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    torch.set_num_threads(cores)
+    dcfg = O.DenoiserCfg(horizon=T, transition_dim=F_OBS, dim=128, dim_mults=(1, 4, 8), n_agents=A,
+                         returns_condition=True, condition_dropout=0.25, history_horizon=HH)
+    c = O.DiffusionCfg(A, T - HH, HH, F_OBS, ACT, K_DIFF, hidden_dim=256, returns_condition=True,
+                       discrete_action=DISCRETE, num_actions=NUM_ACTIONS)
+    shapes = {"model." + k: v for k, v in O.denoiser_param_shapes(dcfg).items()}
+    params = {k: O.closed_form_param(k, s) for k, s in shapes.items()}
+    den, _ = O.split_params(params)
+    sched = O.DDPMSchedule(K_DIFF)
+    b = O.synthetic_batch(episodes, T, A, F_OBS, ACT, HH, discrete=DISCRETE, num_actions=NUM_ACTIONS, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = 0.5 * torch.randn(episodes, T, A, F_OBS, generator=g)
+    ts_all = sched.timesteps.tolist()
+
+    def one(i, x):
+        with torch.no_grad():
+            x = O.apply_conditioning(x, b["cond"])
+            ts = torch.full((episodes,), ts_all[i], dtype=torch.long)
+            eps = O.guided_eps(den, dcfg, c, x, ts, b["returns"])
+            return sched.step(eps, ts_all[i], x, torch.randn(x.shape, generator=g))
+
+    x = one(0, x)                                   # warm-up
+    t0 = time.time()
+    n = 0
+    while n < steps or (time.time() - t0 < seconds_budget * 0.4 and n < 20):
+        x = one(1 + n, x)
+        n += 1
+    dt = time.time() - t0
+    return {"value": episodes / (dt / n * K_DIFF), "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "extrapolated": True,
+            "sample": f"{n} guided denoising steps (2 forwards + posterior each, fp32, torch CPU oracle) on {episodes} "
+                      f"episodes of the same shape after 1 warm-up step: {dt:.1f} s, extrapolated x{K_DIFF}/{n} to K={K_DIFF}"}
+
+
+def launch_ranks(n, argv, script=None, check_devices=True, port=None):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) as children of THIS process,
+    which has made no GPU call yet (torch.cuda.device_count() does not initialise the runtime), through
+    `python -m torch.distributed.run` on 127.0.0.1, and return the job's exit code.  Fewer visible devices than ranks is
+    an error, not a silent 1-rank run.  (The reference has no counterpart: run_scripts/train.py:223,233 pins one GPU.)"""
+    import socket
+    import subprocess
+    if check_devices:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} asked for {n} ranks but only {have} GPU(s) are visible; refusing to run a "
+                  f"smaller job under that label", file=sys.stderr, flush=True)
+            return 2
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,11 +233,18 @@ def main():
                     help="episodes sampled per GPU (BASELINE.json configs[4]: 8192 episodes over 8 GPUs = 1024 per GPU)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="tag",
                     help="named shape (default: BASELINE.json configs[1], the headline workload)")
+    ap.add_argument("--sample-workload", choices=sorted(WORKLOADS), default=None,
+                    help="shape of the sampling leg (default: spread on the headline run = BASELINE.json configs[4], "
+                         "else the training workload)")
     ap.add_argument("--batch", type=int, default=256, help="trajectory windows per GPU per optimizer step")
     args = ap.parse_args()
     select_workload(args.workload, args.batch)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # before anything in this process touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -284,30 +357,56 @@ def main():
                     f"({1e3 * dt_inst / args.steps:.2f} ms/step with the event pairs)")
     train_sps = BATCH * world * args.steps / dt
 
-    # ---- sampling: every rank samples its own shard of episodes with the EMA weights; no collective in the loop
+    # ---- sampling (BASELINE.json configs[4] on the default run): the episode batch is sharded over the ranks
+    # (madiff_amd.sharding.sample_sharded: contiguous slices, each rank replays its own captured K-step loop with the EMA
+    # weights, no collective in the loop) and ONE final gather brings the plans to rank 0; the gather is inside the timed
+    # region.  The sampling shape defaults to spread for the headline run (configs[4] names it) and to the training
+    # workload otherwise (configs[3]: SMAC train + sample).
     sample = None
     if not args.no_sample:
+        from madiff_amd.sharding import sample_sharded
+        sw_name = args.sample_workload or ("spread" if args.workload == "tag" else args.workload)
         sb = args.sample_batch
-        sbatch = synthetic_batch(sb, device, seed=1000 + rank)
+        if sw_name != args.workload:
+            select_workload(sw_name, args.batch)
+            torch.manual_seed(1)
+            sampler = build(device)            # random-init weights of that shape (synthetic, like the training leg)
+            if world > 1:
+                for p_ in sampler.parameters():
+                    dist.broadcast(p_.data, src=0)
+        else:
+            sampler = ema
+        sbatch = synthetic_batch(sb * world, device, seed=1000)          # the whole episode batch, as the evaluator holds it
         cond = {"x": sbatch["cond"]["x"].contiguous(), "masks": sbatch["cond"]["masks"].contiguous()}
         ret = sbatch["returns"].contiguous()
-        assert cond["x"].shape[0] == sb
-        ema.conditional_sample(cond, returns=ret, verbose=False)          # warm-up (allocator, pack cache)
+        sample_sharded(sampler, cond, ret, dst=0)                       # warm-up (allocator, pack cache, graph capture)
         barrier()
         s0 = time.perf_counter()
-        xs = ema.conditional_sample(cond, returns=ret, verbose=False)
+        xs = sample_sharded(sampler, cond, ret, dst=0)
         barrier()
         sdt = time.perf_counter() - s0
         if world > 1:
             tt = torch.tensor([sdt], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             sdt = float(tt.item())
-            gathered = [torch.empty_like(xs) for _ in range(world)] if rank == 0 else None
-            dist.gather(xs, gathered, dst=0)                              # the one final gather
-        sample = {"metric": "DDPM sampled trajectories/sec", "value": sb * world / sdt, "unit": "trajectories/s",
-                  "batch_per_gpu": sb, "k_steps": K_DIFF, "guidance": "2B-batch CFG, w=1.2",
-                  "graph": "one captured step replayed K-2 times", "seconds": sdt,
-                  "finite": bool(torch.isfinite(xs).all().item())}
+        if rank == 0:
+            assert xs.shape[0] == sb * world
+            tps = sb * world / sdt
+            tf = tps * K_DIFF * 2 * FWD_GF_PER_SAMPLE / 1e3 / world      # model TFLOP/s per GPU (2 forwards per step)
+            sample = {"metric": "DDPM sampled trajectories/sec", "value": tps, "unit": "trajectories/s",
+                      "workload": WORKLOAD_DESC, "episodes": sb * world, "episodes_per_gpu": sb, "k_steps": K_DIFF,
+                      "guidance": "2B-batch CFG, w=1.2", "graph": "one captured step replayed K-2 times per rank",
+                      "collectives": "none in the loop; one final gather to rank 0 (inside the timed region)",
+                      "seconds": sdt, "finite": bool(torch.isfinite(xs).all().item()),
+                      "inpainting_exact": bool(torch.equal(xs[:, : HH + 1], cond["x"][:, : HH + 1])),
+                      "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": tf / MFMA_BF16_PEAK_TF,
+                                   "algorithmic_tflop_per_trajectory": K_DIFF * 2 * FWD_GF_PER_SAMPLE / 1e3}}
+            if world == 1 and not args.no_cpu:
+                sample["cpu_baseline"] = cpu_baseline_sample()
+        if sw_name != args.workload:
+            del sampler
+            select_workload(args.workload, args.batch)
 
     if rank == 0:
         dom = max((k for k in summ if "gemm" in k or "conv_taps" in k), key=lambda k: summ[k]["ms"])   # dominant kernel
