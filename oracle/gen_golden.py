@@ -230,6 +230,7 @@ def gen_modules(R):
 # ---------------------------------------------------------------- G2/G3: whole denoiser
 SHAPES = {  # name: (A, T, F, hh)
     "spread": (3, 24, 18, 0), "tag": (3, 24, 16, 0), "ant": (4, 28, 54, 18), "smac": (8, 24, 88, 20),
+    "tag4": (4, 24, 16, 0),     # BASELINE.json configs[1] as named ("4 agents"): the shape bench.py runs
 }
 
 
@@ -274,7 +275,7 @@ def gen_denoiser(R, width, shapes, tag, with_grads):
 def build_diffusion(R, name, width, K, discrete=False, share_inv=True):
     M, D = R["ma_temporal"], R["diffusion"]
     A, T, Fd, hh = SHAPES[name]
-    act = 1 if discrete else {"spread": 5, "tag": 5, "ant": 2, "smac": 1}[name]
+    act = 1 if discrete else {"spread": 5, "tag": 5, "tag4": 5, "ant": 2, "smac": 1}[name]
     nact = 14 if discrete else 0
     net = quiet(M.SharedConvAttentionDeconv, horizon=T, transition_dim=Fd, dim=width, history_horizon=hh,
                 dim_mults=(1, 4, 8), n_agents=A, returns_condition=True, condition_dropout=0.25)
@@ -364,9 +365,126 @@ def gen_masks():
          **{k + ".shape": np.asarray(v.shape) for k, v in out.items()})
 
 
+# ---------------------------------------------------------------- round 2: full width WITH gradients, env_ts
+N_SAMPLES = 96
+
+
+def sample_index(numel: int) -> np.ndarray:
+    """Closed-form pseudo-random positions inside a flattened tensor (tests/test_gpu_parity.py recomputes them)."""
+    i = np.arange(N_SAMPLES, dtype=np.uint64)
+    return ((i * np.uint64(2654435761) + np.uint64(40503)) % np.uint64(numel)).astype(np.int64)
+
+
+def grad_samples(named_grads):
+    """[n_params, N_SAMPLES] gradient elements at sample_index positions: pins individual elements of the big weight
+    gradients (a digest alone would accept a permuted or mis-tiled gradient with the right norm)."""
+    rows = []
+    for _k, g in named_grads:
+        flat = g.detach().reshape(-1)
+        rows.append(flat[torch.from_numpy(sample_index(flat.numel()))].float().numpy())
+    return np.stack(rows)
+
+
+T_DRAWS = [3, 151, 0, 199, 57, 100, 12, 180]
+
+
+def gen_denoiser_grads_w128(R):
+    """g3g: dim-128 denoiser forward + backward (what the bf16 fused conv+GroupNorm kernel, the all-taps data/weight
+    gradient kernels and the GEMM-layout gradient sink compute) for spread (A=3) and the benchmarked tag shape (A=4)."""
+    M = R["ma_temporal"]
+    out = {}
+    for name, B in (("spread", 6), ("tag4", 8)):
+        A, T, Fd, hh = SHAPES[name]
+        net = quiet(M.SharedConvAttentionDeconv, horizon=T, transition_dim=Fd, dim=128, history_horizon=hh,
+                    dim_mults=(1, 4, 8), n_agents=A, returns_condition=True, condition_dropout=0.25)
+        fill_closed_form(net, "model.")
+        x = u(f"g3g.{name}.x", (B, T, A, Fd))
+        t = torch.tensor(T_DRAWS[:B])
+        ret = u(f"g3g.{name}.ret", (B, 1, A), 0.0, 1.0)
+        with Recorder() as rec:
+            xg = x.clone().requires_grad_(True)
+            y = net(xg, t, returns=ret, use_dropout=True)
+        gy = u(f"g3g.{name}.gy", tuple(y.shape))
+        y.backward(gy)
+        named = [(k, p.grad) for k, p in net.named_parameters() if p.grad is not None]
+        names, rows = grad_digest(named)
+        out.update({f"{name}.x": x, f"{name}.t": t, f"{name}.returns": ret, f"{name}.dropout_mask": rec.of("bern")[0],
+                    f"{name}.y_drop": y, f"{name}.gy": gy, f"{name}.gx": xg.grad, f"{name}.gp_names": names,
+                    f"{name}.gp_digest": rows, f"{name}.gp_samples": grad_samples(named),
+                    f"{name}.nograd_names": np.array([k for k, p in net.named_parameters() if p.grad is None])})
+        for k in ("net.final_conv.1.bias", "net.final_conv.0.block.0.bias", "self_attn.0.gamma", "self_attn.1.gamma",
+                  "self_attn.2.gamma", "net.mid_block1.blocks.0.block.2.weight", "net.mid_block1.blocks.0.block.2.bias",
+                  "net.downs.2.1.time_mlp.1.bias", "net.ups.0.0.blocks.0.block.0.bias", "net.returns_mlp.0.weight"):
+            out[f"{name}.gp.{k}"] = dict(net.named_parameters())[k].grad
+    save("g3g_denoiser_w128_grads", **out)
+
+
+def gen_loss_w128(R):
+    """g4w: GaussianDiffusion.loss + backward at dim 128 / hidden 256 on the benchmarked tag shape (A=4)."""
+    out = {}
+    tag, name, B = "tag4", "tag4", 4
+    dif, (A, T, Fd, hh, act, nact) = build_diffusion(R, name, 128, 200)
+    batch = O.synthetic_batch(B, T, A, Fd, act, hh, False, 0, seed=13)
+    with Recorder() as rec:
+        loss, info = dif.loss(**batch)
+        loss.backward()
+    named = [(k, p.grad) for k, p in dif.named_parameters() if p.grad is not None]
+    names, rows = grad_digest(named)
+    out.update({f"{tag}.t": rec.of("randint")[0], f"{tag}.noise": rec.of("randn_like")[0],
+                f"{tag}.dropout_mask": rec.of("bern")[0], f"{tag}.loss": loss.detach(), f"{tag}.gp_names": names,
+                f"{tag}.gp_digest": rows, f"{tag}.gp_samples": grad_samples(named)})
+    for k, v in info.items():
+        out[f"{tag}.info.{k}"] = torch.as_tensor(v).detach()
+    save("g4w_loss_w128", **out)
+
+
+def gen_env_ts(R):
+    """g8: env_ts_condition=True (ma_temporal.py:355-362): an nn.Embedding(max_path_length + 1) lookup of
+    env_timestep[:, history_horizon] -> MLP, concatenated to the embedding.  Small width, forward + gradients."""
+    M = R["ma_temporal"]
+    out = {}
+    name, B, mpl = "ant", 3, 40
+    A, T, Fd, hh = SHAPES[name]
+    net = quiet(M.SharedConvAttentionDeconv, horizon=T, transition_dim=Fd, dim=16, history_horizon=hh,
+                dim_mults=(1, 4, 8), n_agents=A, returns_condition=True, env_ts_condition=True, condition_dropout=0.25,
+                max_path_length=mpl)
+    fill_closed_form(net, "model.")
+    x = u("g8.x", (B, T, A, Fd))
+    t = torch.tensor(T_DRAWS[:B])
+    ret = u("g8.ret", (B, 1, A), 0.0, 1.0)
+    start = torch.tensor([0, 7, mpl - hh])                 # env step of the window start; the last one reaches the pad id
+    env_ts = (start[:, None] + torch.arange(T)[None, :] - hh)
+    env_ts[(env_ts < 0) | (env_ts >= mpl)] = mpl           # datasets/sequence.py / evaluator.py:42-44 convention
+    with torch.no_grad():
+        y_c = net(x, t, returns=ret, env_timestep=env_ts, use_dropout=False)
+        y_u = net(x, t, returns=ret, env_timestep=env_ts, use_dropout=False, force_dropout=True)
+    with Recorder() as rec:
+        xg = x.clone().requires_grad_(True)
+        y = net(xg, t, returns=ret, env_timestep=env_ts, use_dropout=True)
+    gy = u("g8.gy", tuple(y.shape))
+    y.backward(gy)
+    named = [(k, p.grad) for k, p in net.named_parameters() if p.grad is not None]
+    names, rows = grad_digest(named)
+    out.update({"x": x, "t": t, "returns": ret, "env_ts": env_ts, "max_path_length": np.array(mpl), "y_cond": y_c,
+                "y_uncond": y_u, "dropout_mask": rec.of("bern")[0], "y_drop": y, "gy": gy, "gx": xg.grad,
+                "gp_names": names, "gp_digest": rows})
+    for k, p in net.named_parameters():
+        if k.startswith("net.env_ts_mlp"):
+            out["gp." + k] = p.grad
+    save("g8_env_ts", **out)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "masks":
         gen_masks()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":      # only the fixtures added in round 2
+        torch.manual_seed(1234)
+        torch.set_num_threads(8)
+        R = load_reference()
+        gen_denoiser_grads_w128(R)
+        gen_loss_w128(R)
+        gen_env_ts(R)
         return
     torch.manual_seed(1234)
     torch.set_num_threads(8)
@@ -377,6 +495,9 @@ def main():
     gen_denoiser(R, 128, ["spread"], "g3_denoiser_w128", False)
     gen_loss(R)
     gen_sample(R)
+    gen_denoiser_grads_w128(R)
+    gen_loss_w128(R)
+    gen_env_ts(R)
 
 
 if __name__ == "__main__":

@@ -163,3 +163,71 @@ def test_ddim(golden):
     with torch.no_grad():
         x = O.conditional_sample(p, dcfg, c, O.DDIMSchedule(200, 15), cond, T(g[tag + ".returns"]), x_init, [])
     assert rel_err(x, g["ddim15.x"]) < 1e-4
+
+
+# ---------------------------------------------------------------- round-2 fixtures: full width with gradients, env_ts
+SHAPES["tag4"] = (4, 24, 16, 0)          # BASELINE.json configs[1] as named (4 agents): the shape bench.py runs
+
+
+def sample_index(numel, n=96):
+    """Positions oracle/gen_golden.py sampled every parameter gradient at."""
+    i = np.arange(n, dtype=np.uint64)
+    return ((i * np.uint64(2654435761) + np.uint64(40503)) % np.uint64(numel)).astype(np.int64)
+
+
+def test_env_ts_condition(golden):
+    """env_ts_condition=True (ma_temporal.py:355-362): embedding lookup at env_timestep[:, history_horizon]."""
+    g = golden("g8_env_ts")
+    A, Tt, Fd, hh = SHAPES["ant"]
+    cfg = O.DenoiserCfg(horizon=Tt, transition_dim=Fd, dim=16, history_horizon=hh, dim_mults=(1, 4, 8), n_agents=A,
+                        returns_condition=True, env_ts_condition=True, condition_dropout=0.25,
+                        max_path_length=int(g["max_path_length"]))
+    p = {k: O.closed_form_param("model." + k, s) for k, s in O.denoiser_param_shapes(cfg).items()}
+    x, t, r, ets = T(g["x"]), T(g["t"]), T(g["returns"]), T(g["env_ts"])
+    assert rel_err(O.denoiser_forward(p, cfg, x, t, r, env_timestep=ets), g["y_cond"]) < TOL
+    assert rel_err(O.denoiser_forward(p, cfg, x, t, r, None, True, env_timestep=ets), g["y_uncond"]) < TOL
+    pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    y = O.denoiser_forward(pg, cfg, x, t, r, T(g["dropout_mask"]), env_timestep=ets)
+    assert rel_err(y.detach(), g["y_drop"]) < TOL
+    y.backward(T(g["gy"]))
+    for k in g:
+        if k.startswith("gp."):
+            assert rel_err(pg[k[3:]].grad, g[k]) < 2e-5, k
+    assert int(g["env_ts"].max()) == int(g["max_path_length"])      # the pad id is exercised
+
+
+@pytest.mark.parametrize("name", ["spread", "tag4"])
+def test_denoiser_full_width_gradients(golden, name):
+    g = golden("g3g_denoiser_w128_grads")
+    cfg = den_cfg(name, 128)
+    p = {k: O.closed_form_param("model." + k, s).requires_grad_(True) for k, s in O.denoiser_param_shapes(cfg).items()}
+    x, t, r = T(g[name + ".x"]).requires_grad_(True), T(g[name + ".t"]), T(g[name + ".returns"])
+    y = O.denoiser_forward(p, cfg, x, t, r, T(g[name + ".dropout_mask"]))
+    assert rel_err(y.detach(), g[name + ".y_drop"]) < 5e-6
+    y.backward(T(g[name + ".gy"]))
+    assert rel_err(x.grad, g[name + ".gx"]) < 2e-5
+    for n, row, smp in zip(g[name + ".gp_names"], g[name + ".gp_digest"], g[name + ".gp_samples"]):
+        gr = p[str(n)].grad
+        assert abs(gr.double().pow(2).sum().sqrt().item() - row[2]) <= 5e-4 * row[2] + 2e-6, n
+        got = gr.reshape(-1)[torch.from_numpy(sample_index(gr.numel()))].numpy()
+        assert np.abs(got - smp).max() <= 2e-4 * np.abs(gr.numpy()).max() + 3e-6, n   # (+ fp32 noise: key biases have zero gradient)
+    for n in g[name + ".nograd_names"]:
+        assert p[str(n)].grad is None
+
+
+def test_loss_full_width(golden):
+    g = golden("g4w_loss_w128")
+    tag = "tag4"
+    A, Tt, Fd, hh = SHAPES[tag]
+    dcfg, c = den_cfg(tag, 128), dif_cfg("tag", 200, hidden=256)
+    c.n_agents = A
+    p = full_params(dcfg, c)
+    batch = O.synthetic_batch(4, Tt, A, Fd, c.action_dim, hh, False, 0, seed=13)
+    pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss, info, _ = O.diffusion_loss(pg, dcfg, c, O.DDPMSchedule(200), batch["x"], batch["cond"], batch["loss_masks"],
+                                     T(g[tag + ".t"]), T(g[tag + ".noise"]), batch["returns"], T(g[tag + ".dropout_mask"]))
+    assert abs(loss.item() - float(g[tag + ".loss"])) < 5e-6 * abs(float(g[tag + ".loss"]))
+    loss.backward()
+    for n, row in zip(g[tag + ".gp_names"], g[tag + ".gp_digest"]):
+        gr = pg[str(n)].grad.double()
+        assert abs(gr.pow(2).sum().sqrt().item() - row[2]) <= 1e-3 * row[2] + 2e-6, n
