@@ -54,6 +54,12 @@ int madiff_event_create_timed(void** event_out);
 int madiff_event_elapsed_ms(void* start, void* stop, float* ms);
 int madiff_event_record_external(void* event, madiff_stream_t stream);
 int madiff_stream_wait_event(madiff_stream_t stream, void* event);
+/* Inside one stream capture: make `waiter` depend on everything captured so far on `waited` by adding waited's dependency
+ * frontier to waiter's (hipStreamUpdateCaptureDependencies) instead of an event record + wait.  Needed because two side
+ * streams of a capture that have waited on each other's events make hipStreamEndCapture recurse without end on this
+ * runtime.  Returns 1 (nothing done) when the two streams are not both capturing the same graph.
+ * No counterpart in the reference (no graphs there). */
+int madiff_capture_join(madiff_stream_t waiter, madiff_stream_t waited);
 
 /* Implicit-GEMM convolution / linear:
  *   C[m, o] = act( sum_{tap, c} X[src(m, tap), c] * W[o, tap*Cin + c] + bias[o] + rowbias[m / T_out, o] )

@@ -566,6 +566,28 @@ extern "C" int madiff_event_record_external(void* event, hipStream_t stream) {
   if (rc != hipSuccess) return (int)rc;
   return (int)hipStreamUpdateCaptureDependencies(stream, &node, 1, hipStreamSetCaptureDependencies);
 }
+// "waiter waits for everything captured so far on waited", for two streams ALREADY inside the same capture, without
+// hipStreamWaitEvent: waited's dependency frontier is added to waiter's by hand.  Reason: on this runtime every
+// hipStreamWaitEvent by a non-origin capturing stream appends the waiter to the waited stream's list of parallel capture
+// streams, and hip::Stream::EndCapture() recurses over those lists without a visited set: two side streams that have
+// waited on EACH OTHER (in any order, at any distance) make hipStreamEndCapture recurse until the stack overflows
+// (scripts/dbg/capture_topology.cpp topologies 6/7, profiles/r02_capture_topology.txt).  Returns 1 when the streams are
+// not both capturing the same graph (the caller then uses an ordinary event record + wait, which is also how a stream
+// JOINS a capture).
+extern "C" int madiff_capture_join(hipStream_t waiter, hipStream_t waited) {
+  hipStreamCaptureStatus s1 = hipStreamCaptureStatusNone, s2 = hipStreamCaptureStatusNone;
+  unsigned long long id1 = 0, id2 = 0;
+  hipGraph_t g1 = nullptr, g2 = nullptr;
+  const hipGraphNode_t *d1 = nullptr, *d2 = nullptr;
+  size_t n1 = 0, n2 = 0;
+  hipError_t rc = hipStreamGetCaptureInfo_v2(waiter, &s1, &id1, &g1, &d1, &n1);
+  if (rc != hipSuccess) return (int)rc;
+  rc = hipStreamGetCaptureInfo_v2(waited, &s2, &id2, &g2, &d2, &n2);
+  if (rc != hipSuccess) return (int)rc;
+  if (s1 != hipStreamCaptureStatusActive || s2 != hipStreamCaptureStatusActive || id1 != id2 || g1 != g2) return 1;
+  if (n2 == 0) return 0;
+  return (int)hipStreamUpdateCaptureDependencies(waiter, const_cast<hipGraphNode_t*>(d2), n2, hipStreamAddCaptureDependencies);
+}
 extern "C" int madiff_stream_wait_event(hipStream_t stream, void* event) {
   if (!event) return -1;
   return (int)hipStreamWaitEvent(stream, (hipEvent_t)event, 0);

@@ -364,7 +364,7 @@ class GaussianDiffusion(nn.Module):
         if x.is_cuda and not self.train_only_inv and INV_SIDE_STREAM:
             cur = torch.cuda.current_stream()
             side = ops.aux_stream(x.device)
-            side.wait_stream(cur)
+            ops.wait_stream(side, cur)
             with torch.cuda.stream(side):
                 inv_loss, inv_info = self.compute_inv_loss(x, loss_masks, legal_actions)
         if self.train_only_inv:
@@ -379,7 +379,7 @@ class GaussianDiffusion(nn.Module):
         if side is None:
             inv_loss, inv_info = self.compute_inv_loss(x, loss_masks, legal_actions)
         else:
-            cur.wait_stream(side)
+            ops.wait_stream(cur, side)
             for v in [inv_loss, *inv_info.values()]:
                 if torch.is_tensor(v):
                     v.record_stream(cur)

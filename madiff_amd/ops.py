@@ -74,6 +74,18 @@ def stream_is_capturing(st) -> bool:
         return torch.cuda.is_current_stream_capturing()
 
 
+def wait_stream(waiter, waited) -> None:
+    """waiter.wait_stream(waited), safe inside a capture.  When both streams already belong to the same capture the
+    dependency is added by hand (madiff_capture_join): on this runtime side streams of a capture that wait on each
+    other through events make hipStreamEndCapture recurse until the stack overflows.  Outside a
+    capture, and when `waiter` is about to JOIN the capture, it is the ordinary event record + wait."""
+    if waiter.cuda_stream == waited.cuda_stream:
+        return
+    if lib.call_rc("madiff_capture_join", waiter.cuda_stream, waited.cuda_stream) == 0:
+        return
+    waiter.wait_stream(waited)
+
+
 def join_aux_streams(target=None):
     """Make `target` (default: the current stream) wait for everything issued so far on the auxiliary streams.  While
     `target` is capturing, only the auxiliary streams that have joined the same capture are waited for: an event
@@ -87,7 +99,7 @@ def join_aux_streams(target=None):
             continue
         if capturing and not stream_is_capturing(st):
             continue
-        target.wait_stream(st)
+        wait_stream(target, st)
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -372,17 +384,18 @@ def _timed(name: str, flops: float, launch):
 
 
 def graph_capture(graph):
-    """torch.cuda.graph(graph) for the train-step and sampler captures.  With an RCCL process group alive, torch's
-    watchdog thread polls the completion events of recent collectives; under the default capture mode ("global") such a
-    call from another thread while this thread captures is an error that ends in abort() (seen on the 1-rank RCCL test:
-    the process died at a random line of the captured step).  So: let the watchdog retire the finished collectives first
-    (device idle + a few of its poll intervals), and capture in "thread_local" mode, which restricts only the capturing
-    thread.  Kernels launched by the autograd thread onto the capturing stream are captured in either mode."""
-    import time
-    import torch.distributed as dist
+    """torch.cuda.graph(graph) for the train-step and sampler captures, in "thread_local" capture-error mode.
+
+    Why: with an RCCL process group alive, torch's ProcessGroupNCCL watchdog THREAD polls the completion events of recent
+    collectives with hipEventQuery (ATen/hip/HIPEvent.h query()).  While any stream captures in the default "global" mode
+    this runtime answers hipEventQuery / hipStreamQuery / hipEventSynchronize / hipMalloc from ANY thread with error 900
+    (hipErrorStreamCaptureUnsupported) and invalidates the capture (hipStreamEndCapture -> 901); query() passes every error
+    but hipErrorNotReady to C10_HIP_CHECK, which throws inside the watchdog thread -> std::terminate -> abort() at whatever
+    line the capturing thread happens to be (round 1's "abort at random lines").  In "thread_local" mode the same calls
+    from other threads succeed and the capture stays valid (scripts/dbg/capture_foreign_thread.cpp,
+    profiles/r02_capture_foreign_thread.txt).  So thread_local IS the fix; nothing is waited for or slept on.
+    Kernels launched by the autograd thread onto the capturing stream are captured in either mode."""
     torch.cuda.synchronize()
-    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-        time.sleep(0.5)
     return torch.cuda.graph(graph, capture_error_mode="thread_local")
 
 
@@ -808,7 +821,7 @@ def _param_grads_side(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
         return _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw)
     cur = torch.cuda.current_stream()
     side = aux_stream(dy.device, "wgrad")
-    side.wait_stream(cur)
+    wait_stream(side, cur)
     sink.deferred = []
     try:
         with torch.cuda.stream(side):

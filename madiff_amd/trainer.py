@@ -55,6 +55,11 @@ class FlatAdamEMA:
         # all-reduce), so the HBM-bound Adam/EMA pass runs under the MFMA-bound rest of backward instead of after it
         self.overlap = os.environ.get("MADIFF_OVERLAP_ADAM", "1") != "0"
         self._announced = None           # (do_ema, device_state) of the step whose backward is running (begin_step)
+        self._main_stream = None
+        # data-parallel capture: put the bucket event nodes on the MAIN branch, i.e. rejoin the parallel branches into it
+        # at every bucket (a serialisation point per bucket; default off.  Kept as a tested alternative topology, see
+        # DESIGN.md section 5 "capture failures")
+        self.bucket_events_on_main = os.environ.get("MADIFF_BUCKET_EVENTS_ON_MAIN") == "1"
 
     # ------------------------------------------------------------------ setup after the first backward
     def _materialise(self):
@@ -210,6 +215,18 @@ class FlatAdamEMA:
                  None if device_state is None else device_state.data_ptr(), self.flat_p16.data_ptr() + 2 * lo, 3,
                  stream.cuda_stream)
 
+    def _order_behind_producers(self, tgt):
+        """Make `tgt` wait for every stream a member of the bucket may have been produced on: the stream that is current
+        now, the step's main stream and the parallel branches (ops.aux_stream)."""
+        cur = torch.cuda.current_stream()
+        for st in (cur, self._main_stream):
+            if st is None or st.cuda_stream == tgt.cuda_stream:
+                continue
+            if ops.stream_is_capturing(tgt) and not ops.stream_is_capturing(st):
+                continue
+            ops.wait_stream(tgt, st)
+        ops.join_aux_streams(tgt)
+
     def _launch_bucket(self, b):
         if not self.dp:
             # single process: nothing to reduce; the bucket's optimizer slice goes onto the "wgrad" branch
@@ -217,9 +234,7 @@ class FlatAdamEMA:
                 return                        # (per-launch event timing: keep the timed kernels alone on the GPU)
             cur = torch.cuda.current_stream()
             tgt = ops.aux_stream(cur.device, "wgrad") if ops.WGRAD_SIDE_STREAM else cur
-            if tgt.cuda_stream != cur.cuda_stream:
-                tgt.wait_stream(cur)          # every member's data-gradient launch (it reads the weights) is behind us
-            ops.join_aux_streams(tgt)
+            self._order_behind_producers(tgt)  # every member's data-gradient launch (it reads the weights) is behind us
             self._adam_slice(b["lo"], b["hi"], *self._announced, tgt)
             b["opt"] = True
             return
@@ -232,10 +247,8 @@ class FlatAdamEMA:
             # branch, which rejoins the main branch once, at the end of the step.  (Joining the branches into the
             # main stream at every bucket instead made hipStreamEndCapture crash.)
             cur = torch.cuda.current_stream()
-            tgt = ops.aux_stream(cur.device, "wgrad") if ops.WGRAD_SIDE_STREAM else cur
-            if tgt.cuda_stream != cur.cuda_stream:
-                tgt.wait_stream(cur)
-            ops.join_aux_streams(tgt)                 # members may have been produced on a parallel branch
+            tgt = ops.aux_stream(cur.device, "wgrad") if (ops.WGRAD_SIDE_STREAM and not self.bucket_events_on_main) else cur
+            self._order_behind_producers(tgt)         # members may have been produced on a parallel branch
             bi = self.buckets.index(b)
             lib.call("madiff_event_record_external", self._graph_events[bi], tgt.cuda_stream)
             self._graph_order.append(bi)
@@ -243,8 +256,7 @@ class FlatAdamEMA:
             return
         g = self.flat_g[b["lo"]:b["hi"]]
         if self._comm_stream is not None:
-            self._comm_stream.wait_stream(torch.cuda.current_stream())
-            ops.join_aux_streams(self._comm_stream)  # members of the bucket may have been produced on a side branch
+            self._order_behind_producers(self._comm_stream)   # members may have been produced on a side branch
             with torch.cuda.stream(self._comm_stream):
                 b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 if self._announced is not None and self.use_hip and self.overlap and ops.TIMER is None:
@@ -268,6 +280,9 @@ class FlatAdamEMA:
         """Only the last micro-batch of an accumulation group triggers the all-reduce (no_sync equivalent)."""
         self._sync_this_backward = flag
         self._notified = set()
+        # the stream the step is issued on: a bucket may be completed from code running on a parallel branch (the
+        # inverse-dynamics backward runs on its own stream) while other members were produced on this one
+        self._main_stream = torch.cuda.current_stream() if (self.flat_p is not None and self.flat_p.is_cuda) else None
         if flag:
             for b in self.buckets:
                 b["pending"] = len(b["members"])

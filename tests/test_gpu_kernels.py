@@ -398,13 +398,19 @@ def test_flat_optimizer_with_gradient_sink_matches_torch_adam():
         ops.set_precision("bf16")
 
 
-@pytest.mark.parametrize("dp", [False, True], ids=["single", "dp_1rank_rccl"])
-def test_graphed_train_step_matches_eager_steps(dp):
+@pytest.mark.parametrize("dp,topology", [(False, "default"), (True, "default"), (True, "no_wgrad_branch"),
+                                         (True, "rejoin_per_bucket"), (False, "no_wgrad_branch")],
+                         ids=["single", "dp_1rank_rccl", "dp_no_wgrad_branch", "dp_rejoin_per_bucket", "single_no_wgrad_branch"])
+def test_graphed_train_step_matches_eager_steps(dp, topology):
     """GraphedTrainStep (loss fwd + bwd + fused Adam/EMA replayed from one hipGraph) against the eager train_step on a
     twin model with the same fixed draws: identical launches, so parameters and EMA must agree to rounding.
     dp: the data-parallel form of the step (graph = forward + backward with one graph-external event node per gradient
     bucket; RCCL all-reduce of each bucket issued eagerly on the communication stream after the replay; eager Adam),
-    exercised in a 1-rank RCCL group (MADIFF_FORCE_DP keeps the bucket machinery on at world_size 1)."""
+    exercised in a 1-rank RCCL group (MADIFF_FORCE_DP keeps the bucket machinery on at world_size 1).
+    topology: other shapes of the captured graph around the hand-made event-record nodes -- without the parameter-
+    gradient branch (MADIFF_WGRAD_SIDE_STREAM=0: event nodes on the main stream, the inverse-dynamics branch joined at
+    each), and with the branches rejoined into the MAIN stream at every bucket (the topology whose first version crashed
+    hipStreamEndCapture in round 1 because it also waited on streams outside the capture)."""
     import copy
     import os
     import torch.distributed as dist
@@ -415,6 +421,8 @@ def test_graphed_train_step_matches_eager_steps(dp):
     from oracle import madiff_oracle as O
     dev = _dev()
     ops.set_precision("fp32")
+    side0 = ops.WGRAD_SIDE_STREAM
+    ops.WGRAD_SIDE_STREAM = side0 and topology != "no_wgrad_branch"
     if dp:
         os.environ["MADIFF_FORCE_DP"] = "1"
         if not dist.is_initialized():
@@ -438,6 +446,7 @@ def test_graphed_train_step_matches_eager_steps(dp):
             m = copy.deepcopy(dif)
             ema = copy.deepcopy(m)
             opt = FlatAdamEMA(m, ema, lr=1e-3, ema_decay=0.9, bucket_mb=0.25)
+            opt.bucket_events_on_main = topology == "rejoin_per_bucket"
             train_step(m, opt, [{**batch, **draws}], do_ema=2)          # materialises the flat buffers
             if mode == "eager":
                 for i in range(4):
@@ -459,6 +468,7 @@ def test_graphed_train_step_matches_eager_steps(dp):
         assert rel_err(e1.cpu(), e0.cpu()) < 3e-5
     finally:
         ops.SINK = None
+        ops.WGRAD_SIDE_STREAM = side0
         ops.set_precision("bf16")
         os.environ.pop("MADIFF_FORCE_DP", None)
         if dp and dist.is_initialized():
