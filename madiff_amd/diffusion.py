@@ -101,6 +101,11 @@ class GaussianDiffusion(nn.Module):
         if not use_inv_dyn or not predict_epsilon or returns_loss_guided or value_diffusion_model is not None:
             raise NotImplementedError("only the configuration every exp_spec uses is on the hot path: "
                                       "use_inv_dyn=True, predict_epsilon=True, no value guidance (SURVEY.md section 2)")
+        if opponent_loss_weight is not None:
+            # diffusion.py:315-325 re-weights the loss of the opponents of cond["agent_idx"]; no exp_spec sets it, and
+            # silently ignoring it would train a different objective.  (state_loss_weight is stored and never read by the
+            # reference either, diffusion.py:149-172.)
+            raise NotImplementedError("opponent_loss_weight is not on the hot path (no exp_spec sets it)")
         super().__init__()
         self.n_agents = n_agents
         self.horizon = horizon

@@ -125,7 +125,7 @@ class Trainer(object):
                  gradient_accumulate_every=2, step_start_ema=2000, update_ema_every=10, log_freq=100, sample_freq=1000,
                  save_freq=1000, label_freq=100000, eval_freq=100000, save_parallel=False, n_reference=8, bucket=None,
                  train_device="cuda", save_checkpoints=False, use_graph: Optional[bool] = None, bucket_mb: float = 32.0,
-                 shuffle: bool = True, seed: int = 0):
+                 shuffle: bool = True, seed: int = 0, allow_eager_fallback: Optional[bool] = None):
         """Reference arguments (training.py:43-64) plus: use_graph (None = replay the step from a hipGraph on a GPU),
         bucket_mb (gradient bucket size of the data-parallel all-reduce / optimizer slices), shuffle, seed.
         The reference's DataLoader keeps the smaller last batch of an epoch; a replayed graph (and equal work per
@@ -149,6 +149,9 @@ class Trainer(object):
         self.dataset = dataset
         on_gpu = torch.device(train_device).type == "cuda"
         self.use_graph = on_gpu if use_graph is None else use_graph
+        # a failed capture of the train step raises unless this is set (then all ranks drop to the eager step together)
+        self.allow_eager_fallback = (os.environ.get("MADIFF_ALLOW_EAGER_FALLBACK") == "1"
+                                     if allow_eager_fallback is None else bool(allow_eager_fallback))
         if dataset is not None:
             sampler = None
             if self.world > 1:
@@ -211,17 +214,38 @@ class Trainer(object):
         # constructor of the graphed step (eagerly, on its capture stream), which then captures the step once
         if self.use_graph and opt.use_hip and self._eager_steps >= 2 and batches[0]["x"].is_cuda:
             done_before = opt.step_count
+            err, graphed = None, None
             try:
-                self._graphed = GraphedTrainStep(self.model, opt, batches, warm_do_ema=mode)
-                return self._graphed.first
+                graphed = GraphedTrainStep(self.model, opt, batches, warm_do_ema=mode)
             except Exception as e:                      # noqa: BLE001
-                logger.print(f"[ utils/training ] hipGraph capture of the train step failed ({e!r}); staying eager")
-                self.use_graph, self._graphed = False, None
-                if opt.step_count > done_before:        # the constructor's eager step did happen before the failure
-                    torch.cuda.synchronize()
-                    with torch.no_grad():
-                        loss, infos = self.model.loss(**batches[-1])
-                    return loss.detach(), infos
+                err = e
+                opt._announced = None                   # nothing of an interrupted capture may leak into the next step
+                opt._graph_order = []
+            ok = err is None
+            if self.world > 1:
+                # every rank must take the same path: a rank that replays while another issues the eager step would
+                # pair its per-bucket all-reduces (capture order) with the other's (hook order)
+                import torch.distributed as dist
+                flag = torch.tensor([1 if ok else 0], device=batches[0]["x"].device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(int(flag.item()))
+            if ok:
+                self._graphed = graphed
+                return graphed.first
+            if not self.allow_eager_fallback:
+                # a capture regression must not hide behind a slower run
+                raise RuntimeError("hipGraph capture of the train step failed"
+                                   + ("" if err is not None else " on another rank")
+                                   + "; pass allow_eager_fallback=True (or MADIFF_ALLOW_EAGER_FALLBACK=1) to train with "
+                                     "eagerly issued steps instead") from err
+            logger.print(f"[ utils/training ] hipGraph capture of the train step failed ({err!r}); staying eager")
+            self.use_graph, self._graphed = False, None
+            del graphed
+            if opt.step_count > done_before:            # the constructor's eager step did happen before the failure
+                torch.cuda.synchronize()
+                with torch.no_grad():
+                    loss, infos = self.model.loss(**batches[-1])
+                return loss.detach(), infos
         out = train_step(self.model, opt, batches, do_ema=mode)
         self._eager_steps += 1
         return out
