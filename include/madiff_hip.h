@@ -98,7 +98,10 @@ int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, int taps, int
  * library's choice; 0..3 = one workgroup per (O x C, tap) tile {128x128, 128x64, 64x128, 64x64}; 4..7 = ALL taps of a
  * stride-1 "same" k5 convolution in one pass (operands staged once per K-step, tap shift applied by the transposing LDS
  * reads) with tiles {64x64, 64x64, 128x64, 128x64} and {2, 3, 2, 3} LDS stages -- these return 1 (nothing launched) when
- * the layer is not such a convolution or its sequence length divides neither 32 nor 96.  splits: number of slices the
+ * the layer is not such a convolution or its sequence length divides neither 32 nor 96; 8, 9 = the same 64x64 all-taps
+ * tile on EIGHT waves ({2, 3} LDS stages): the reduction rows of every K-step are split over two wave groups whose partial
+ * tiles are combined in LDS, so 256 tiles fill the chip without a reduction split and dW is updated by plain
+ * read-modify-write instead of fp32 atomics.  splits: number of slices the
  * reduction over rows is cut into (slices combine with fp32 atomics), <= 0 = library's choice. */
 int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,
                       int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,

@@ -500,11 +500,11 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
                                  int ldx2, int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride,
                                  int pad, int tr, float* dW, int ldw, int Nout, int accumulate, int tile, int splits,
                                  hipStream_t stream) {
-  static const int kBO[8] = {128, 128, 64, 64, 64, 64, 128, 128}, kBC[8] = {128, 64, 128, 64, 64, 64, 64, 64};
+  static const int kBO[10] = {128, 128, 64, 64, 64, 64, 128, 128, 64, 64}, kBC[10] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 64};
   const int es = dtype == MADIFF_BF16 ? 2 : 4;
   if (M <= 0 || Nout <= 0) return 0;
   if (check_rowmap(T_out, T_in, stride, pad, tr) || Cin <= 0 || Cin % 32 || taps <= 0 || ldw < taps * Cin ||
-      Ycols % 32 || ldy < Ycols || (ldy * es) % 16 || (ldx * es) % 16 || M % T_out || tile >= 8)
+      Ycols % 32 || ldy < Ycols || (ldy * es) % 16 || (ldx * es) % 16 || M % T_out || tile >= 10)
     return -1;
   if (X2 == nullptr) Csplit = Cin;
   if (Csplit > Cin || ldx < Csplit || (X2 && (Csplit % 128 || ldx2 < Cin - Csplit || (ldx2 * es) % 16))) return -1;
@@ -521,7 +521,7 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
   const int BO = kBO[tile], BC = kBC[tile];
   const bool all_taps = tile >= 4;
   p.ctiles = (Cin + BC - 1) / BC;
-  const int KR = all_taps ? 32 * nq : (dma ? 64 : (dtype == MADIFF_BF16 ? 32 : 16));
+  const int KR = all_taps ? (tile >= 8 ? 64 : 32) * nq : (dma ? 64 : (dtype == MADIFF_BF16 ? 32 : 16));
   int total_steps = (M + KR - 1) / KR;
   int tiles = ((Nout + BO - 1) / BO) * p.ctiles * (all_taps ? 1 : taps);
   if (splits <= 0) {

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256, (BO >= 128 ? 1 : 2)) void gemm_wgrad_taps_bf16
   constexpr int KR = 32 * NQ;
   constexpr int MI = BO / 32, NJ = BC / 32;
   constexpr int Y_BYTES = KR * BO * 2, X_BYTES = KR * BC * 2;
-  constexpr int ZERO_OFF = Y_BYTES + X_BYTES;            // 128 zero bytes behind the tiles of every stage
+  constexpr int ZERO_OFF = Y_BYTES + X_BYTES;            // 256 zero bytes behind the tiles of every stage
   constexpr int BUF_BYTES = ZERO_OFF + 1024;             // (stages stay 1 KB aligned for the DMA pieces)
   constexpr int YCH = BO / 8;                            // chunks per dY row (8 or 16)
   constexpr int YRP = 64 / YCH;                          // rows per DMA piece
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, (BO >= 128 ? 1 : 2)) void gemm_wgrad_taps_bf16
   if (s_end > total_steps) s_end = total_steps;
   if (s_begin >= s_end) return;
   const int nsteps = s_end - s_begin;
-  if (tid < 32 * D) ((float*)(smem + (tid >> 5) * BUF_BYTES + ZERO_OFF))[tid & 31] = 0.f;
+  if (tid < 64 * D) ((float*)(smem + (tid >> 6) * BUF_BYTES + ZERO_OFF))[tid & 63] = 0.f;   // 256 zero bytes per stage
   __syncthreads();
 
   const unsigned char* xsrc = (const unsigned char*)p.X;
@@ -622,8 +622,10 @@ __global__ __launch_bounds__(256, (BO >= 128 ? 1 : 2)) void gemm_wgrad_taps_bf16
 #pragma unroll
       for (int k = 0; k < TAPS; k++) {
         const int ts = t + k - pad, rs = r + k - pad;       // KR % T == 0: a valid shifted row stays inside the K-step
-        xoff[q][h][k] = (ts >= 0 && ts < T) ? Y_BYTES + rs * (BC * 2) + (((4 * wc + (tp >> 1)) ^ tr_swz<BC>(rs)) << 4) + o8
-                                             : ZERO_OFF + ((tp >> 1) << 4) + o8;
+        // (a lane whose shifted row leaves its sequence reads zeros placed at the SAME bank position the real row would
+        // have had: a fixed zero address would collide with the valid lanes of the same half-wave on its banks)
+        const int nat = rs * (BC * 2) + (((4 * wc + (tp >> 1)) ^ tr_swz<BC>(rs)) << 4) + o8;
+        xoff[q][h][k] = (ts >= 0 && ts < T) ? Y_BYTES + nat : ZERO_OFF + (nat & 255);
       }
     }
 
@@ -715,8 +717,235 @@ __global__ __launch_bounds__(256, (BO >= 128 ? 1 : 2)) void gemm_wgrad_taps_bf16
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// All-taps weight gradient, 8-wave form (variants 8, 9): the same 64 x 64 x TAPS output tile per workgroup, but the
+// reduction rows of every K-step are split over TWO groups of four waves inside the workgroup (group g takes the 32-row
+// chunks [g*NQ, (g+1)*NQ) of a K-step of KR = 64*NQ rows), and the two partial tiles are combined through LDS at the end.
+// Why: with one 4-wave workgroup per tile a 1024 x 1024 k5 layer has only 256 tiles, so the 4-wave kernel needs a
+// split-K of 2 to give every SIMD two waves -- and then every output element is added with an fp32 atomic twice
+// (2 x 21 MB per layer at the ~1.3 TB/s chip-wide atomic rate, issued by all workgroups at the same moment at the end:
+// a ~30 us tail on an 85 us kernel).  Here 256 workgroups of 8 waves fill the chip without a split, and the tile is
+// added to the live gradient by plain read-modify-write 64-byte row segments (splits == 1) -- no atomics at all.
+// ------------------------------------------------------------------------------------------------
+template <int TAPS, int NQ, int D>
+__global__ __launch_bounds__(512) void gemm_wgrad_taps8_bf16_kernel(GemmWgradParams p) {
+  constexpr int BO = 64, BC = 64, KG = 2;
+  constexpr int KR = 32 * NQ * KG;
+  constexpr int MI = BO / 32, NJ = BC / 32;
+  constexpr int Y_BYTES = KR * BO * 2, X_BYTES = KR * BC * 2;
+  constexpr int ZERO_OFF = Y_BYTES + X_BYTES;
+  constexpr int BUF_BYTES = ZERO_OFF + 1024;
+  constexpr int NW = 4 * KG;
+  constexpr int YCH = BO / 8, YRP = 64 / YCH;               // chunks per dY row, rows per 1 KB DMA piece
+  constexpr int YP = KR / YRP / NW, XP = KR / 8 / NW;       // pieces per wave per stage
+  static_assert((KR / YRP) % NW == 0 && (KR / 8) % NW == 0, "pieces must split evenly over the waves");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[D * BUF_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, w4 = wave & 3;
+  const int wn = w4 >> 1, wc = w4 & 1;
+  const int n0 = blockIdx.x * BO, c0 = blockIdx.y * BC;
+  const int T = p.rm.T_out, pad = p.rm.pad;
+  const int total_steps = (p.M + KR - 1) / KR;
+  const int s_begin = blockIdx.z * p.steps_per_split;
+  int s_end = s_begin + p.steps_per_split;
+  if (s_end > total_steps) s_end = total_steps;
+  if (s_begin >= s_end) return;
+  const int nsteps = s_end - s_begin;
+  if (tid < 64 * D) ((float*)(smem + (tid >> 6) * BUF_BYTES + ZERO_OFF))[tid & 63] = 0.f;   // 256 zero bytes per stage
+  __syncthreads();
+
+  const unsigned char* xsrc = (const unsigned char*)p.X;
+  int ldx = p.ldx, cx = c0, cmax = p.Csplit;
+  if (c0 >= p.Csplit) { xsrc = (const unsigned char*)p.X2; ldx = p.ldx2; cx = c0 - p.Csplit; cmax = p.Cin - p.Csplit; }
+
+  int yrow[YP], xrow[XP];
+  const unsigned char* ysrc0[YP];
+  const unsigned char* xsrc0[XP];
+#pragma unroll
+  for (int j = 0; j < YP; j++) {
+    yrow[j] = (YP * wave + j) * YRP + lane / YCH;
+    int ch = (lane % YCH) ^ tr_swz<BO>(yrow[j]);
+    ysrc0[j] = n0 + ch * 8 < p.Ycols ? (const unsigned char*)p.dY + ((size_t)yrow[j] * p.ldy + n0 + ch * 8) * 2 : nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < XP; j++) {
+    xrow[j] = (XP * wave + j) * 8 + (lane >> 3);
+    int ch = (lane & 7) ^ tr_swz<BC>(xrow[j]);
+    xsrc0[j] = cx + ch * 8 < cmax ? xsrc + ((size_t)xrow[j] * ldx + cx + ch * 8) * 2 : nullptr;
+  }
+  const unsigned char* zero = g_zero_page + (lane & 15) * 16;
+  auto issue = [&](int buf, int s) {
+    unsigned char* base = &smem[buf * BUF_BYTES];
+    const size_t m0 = (size_t)s * KR;
+#pragma unroll
+    for (int j = 0; j < YP; j++) {
+      const unsigned char* gsrc = (ysrc0[j] && m0 + yrow[j] < (size_t)p.M) ? ysrc0[j] + m0 * p.ldy * 2 : zero;
+      dma16(gsrc, lds_u32(base + (YP * wave + j) * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+      const unsigned char* gsrc = (xsrc0[j] && m0 + xrow[j] < (size_t)p.M) ? xsrc0[j] + m0 * ldx * 2 : zero;
+      dma16(gsrc, lds_u32(base + Y_BYTES + (XP * wave + j) * 1024));
+    }
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tq = fr >> 2, tp = fr & 3;
+  const int o8 = 8 * (tp & 1);
+  // loop-invariant LDS offsets of the fragment reads, two 16-bit offsets (h = 0 | h = 1 << 16) per register: dY offsets are
+  // relative to the stage, X offsets to the X tile (the zero block sits right behind it: X_BYTES + 255 < 65536)
+  static_assert(Y_BYTES < 65536 && X_BYTES + 256 < 65536, "16-bit fragment offsets");
+  unsigned yoff[NQ], xoff[NQ][TAPS];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    unsigned yo[2], xo[2][TAPS];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int r = 32 * (g * NQ + q) + 8 * fq + tq + 4 * h;    // this wave group's rows of the K-step
+      yo[h] = r * (BO * 2) + ((((YCH / 2) * wn + (tp >> 1)) ^ tr_swz<BO>(r)) << 4) + o8;
+      const int t = r % T;
+#pragma unroll
+      for (int k = 0; k < TAPS; k++) {
+        const int ts = t + k - pad, rs = r + k - pad;           // KR % T == 0: a valid shifted row stays inside the K-step
+        // (a lane whose shifted row leaves its sequence reads zeros placed at the SAME bank position the real row would
+        // have had: a fixed zero address would collide with the valid lanes of the same half-wave on its banks)
+        const int nat = rs * (BC * 2) + (((4 * wc + (tp >> 1)) ^ tr_swz<BC>(rs)) << 4) + o8;
+        xo[h][k] = (ts >= 0 && ts < T) ? nat : X_BYTES + (nat & 255);
+      }
+    }
+    yoff[q] = yo[0] | (yo[1] << 16);
+#pragma unroll
+    for (int k = 0; k < TAPS; k++) xoff[q][k] = xo[0][k] | (xo[1][k] << 16);
+  }
+
+  f32x4 acc[TAPS][MI][NJ];
+#pragma unroll
+  for (int k = 0; k < TAPS; k++)
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[k][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  constexpr int PIECES = YP + XP;
+  int issued = 0, ibuf = 0;
+#pragma unroll
+  for (int d = 0; d < D - 1; d++)
+    if (d < nsteps) { issue(ibuf, s_begin + issued); ++issued; if (++ibuf == D) ibuf = 0; }
+  int buf = 0;
+  for (int s = 0; s < nsteps; s++) {
+    if (s + D - 1 <= nsteps) wait_vmcnt<(D - 2) * PIECES>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (issued < nsteps) { issue(ibuf, s_begin + issued); ++issued; if (++ibuf == D) ibuf = 0; }
+    const unsigned char* B0 = &smem[buf * BUF_BYTES];
+    if (++buf == D) buf = 0;
+    const unsigned char* BX = B0 + Y_BYTES;
+    auto load_a = [&](bf16x8 (&a)[MI], const int q) {
+      unsigned pk = yoff[q];
+      asm volatile("" : "+v"(pk));          // keep the unpacked addresses out of the loop-invariant set (registers)
+      const unsigned o0 = pk & 0xffffu, o1 = pk >> 16;
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (o0 ^ (i << 5))));
+        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(B0 + (o1 ^ (i << 5))));
+        a[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    };
+    auto load_b = [&](bf16x8 (&b)[NJ], const int q, const int k) {
+      unsigned pk = xoff[q][k];
+      asm volatile("" : "+v"(pk));
+      const unsigned o0 = pk & 0xffffu, o1 = pk >> 16;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(BX + (o0 ^ (j << 5))));
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(BX + (o1 ^ (j << 5))));
+        b[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    };
+    // fragment pipeline inside a stage, two positions deep: while the 4 MFMAs of position t = (chunk q, tap k) run, the X
+    // fragments of position t+2 are being read (three register sets); 4 MFMAs = 64 cycles alone do not cover one LDS
+    // round trip under load.  The dY fragments of chunk q+1 are read at the same distance.
+    bf16x8 a[2][MI], b[3][NJ];
+    load_a(a[0], 0);
+    load_b(b[0], 0, 0);
+    load_b(b[1], 0, 1);
+#pragma unroll
+    for (int t = 0; t < NQ * TAPS; t++) {
+      const int q = t / TAPS, k = t % TAPS;
+      const int t2 = t + 2, q2 = t2 / TAPS, k2 = t2 % TAPS;
+      __builtin_amdgcn_sched_barrier(0);
+      if (t2 < NQ * TAPS) {
+        if (k2 == 0) load_a(a[q2 & 1], q2);
+        load_b(b[t2 % 3], q2, k2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+          acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q & 1][i], b[t % 3][j], acc[k][i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- combine the two groups' partial tiles through LDS.  The (tap, i) slices of a round are split between the groups;
+  // each group hands the other one the slices it does not own, then adds what it received and updates global memory.
+  // Rounds (taps [0, TSPLIT) then [TSPLIT, TAPS)) keep the exchange inside the staging memory.
+  constexpr int TSPLIT = TAPS;
+  static_assert(((TSPLIT * MI + 1) / 2) * 2 * NJ * 4 * 256 * 4 <= D * BUF_BYTES, "the partial-tile exchange reuses the staging memory");
+  float* red = (float*)smem;
+  const int t4 = tid & 255;
+#pragma unroll
+  for (int round = 0; round < (TSPLIT < TAPS ? 2 : 1); round++) {
+    const int k0 = round == 0 ? 0 : TSPLIT, k1 = round == 0 ? TSPLIT : TAPS;
+    const int NS = (k1 - k0) * MI, HALF = (NS + 1) / 2;     // slices 0 .. HALF-1 of the round belong to group 0
+    __syncthreads();                                        // operand stages / the previous round's exchange are done with
+#pragma unroll
+    for (int k = 0; k < TAPS; k++)
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        if (k < k0 || k >= k1) continue;
+        const int sl = (k - k0) * MI + i, owner = sl < HALF ? 0 : 1;
+        if (owner == g) continue;
+        const int slot = owner == 0 ? sl : sl - HALF;
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) red[((owner * HALF + slot) * NJ * 4 + j * 4 + r) * 256 + t4] = acc[k][i][j][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TAPS; k++)
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        if (k < k0 || k >= k1) continue;
+        const int sl = (k - k0) * MI + i, owner = sl < HALF ? 0 : 1;
+        if (owner != g) continue;
+        const int slot = owner == 0 ? sl : sl - HALF;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int n = n0 + wn * (BO / 2) + i * 16 + fq * 4 + r;
+#pragma unroll
+          for (int j = 0; j < NJ; j++) {
+            const int c = c0 + wc * (BC / 2) + j * 16 + fr;
+            const float v = acc[k][i][j][r] + red[((owner * HALF + slot) * NJ * 4 + j * 4 + r) * 256 + t4];
+            if (n >= p.Nout || c >= p.Cin) continue;
+            float* dst = p.dW + (size_t)n * p.ldw + (size_t)k * p.Cin + c;
+            if (p.splits > 1) atomicAdd(dst, v);
+            else if (p.accumulate) *dst += v;
+            else *dst = v;
+          }
+        }
+      }
+  }
+}
+
 // variant ids 4..7 of madiff_gemm_wgrad: all-taps kernel, {64x64, 128x64} (O x C) x {2, 3} LDS stages; nq = 32-row
-// chunks per K-step (1 or 3), chosen by the caller from the sequence length
+// chunks per K-step (1 or 3), chosen by the caller from the sequence length.  Variants 8, 9: the 8-wave form (two wave
+// groups split each K-step of 64*nq rows) with 2 / 3 LDS stages.  (A 128 x 64 tile with 64 x 32 x 5-tap wave tiles was
+// built and measured in round 2: 78 us against 72 us on the 1024 x 1024 layer -- not kept.)
 extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_wgrad_taps_bf16(const void* params, int variant, int nq,
                                                                                         int gx, int gy, int gz,
                                                                                         hipStream_t stream) {
@@ -728,14 +957,22 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_wgrad_ta
     if (nq == 3) hipLaunchKernelGGL((gemm_wgrad_taps_bf16_kernel<BO_, 64, 5, 3, D_>), grid, dim3(256), 0, stream, p);   \
     else hipLaunchKernelGGL((gemm_wgrad_taps_bf16_kernel<BO_, 64, 5, 1, D_ + 1>), grid, dim3(256), 0, stream, p);       \
     break;
+#define MADIFF_WT8(V, D_, D1_)                                                                                          \
+  case V:                                                                                                               \
+    if (nq == 3) hipLaunchKernelGGL((gemm_wgrad_taps8_bf16_kernel<5, 3, D_>), grid, dim3(512), 0, stream, p);           \
+    else hipLaunchKernelGGL((gemm_wgrad_taps8_bf16_kernel<5, 1, D1_>), grid, dim3(512), 0, stream, p);                  \
+    break;
   switch (variant) {
     MADIFF_WT(4, 64, 2)
     MADIFF_WT(5, 64, 3)
     MADIFF_WT(6, 128, 2)
     MADIFF_WT(7, 128, 3)
+    MADIFF_WT8(8, 2, 6)
+    MADIFF_WT8(9, 3, 7)
     default: return -1;
   }
 #undef MADIFF_WT
+#undef MADIFF_WT8
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

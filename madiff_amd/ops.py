@@ -496,8 +496,10 @@ def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncol
     return gx.to(act_dtype()) if ksplit > 1 else gx
 
 
-# variants of madiff_gemm_wgrad: (O tile, C tile, all taps in one pass?); 4..7 = {64x64, 128x64} x {2, 3} LDS stages
-_WGRAD_TILES = ((128, 128, 0), (128, 64, 0), (64, 128, 0), (64, 64, 0), (64, 64, 1), (64, 64, 1), (128, 64, 1), (128, 64, 1))
+# variants of madiff_gemm_wgrad: (O tile, C tile, all taps in one pass?); 4..7 = {64x64, 128x64} x {2, 3} LDS stages;
+# 8, 9 = the 8-wave all-taps form (reduction rows of a K-step split over two wave groups, combined in LDS)
+_WGRAD_TILES = ((128, 128, 0), (128, 64, 0), (64, 128, 0), (64, 64, 0), (64, 64, 1), (64, 64, 1), (128, 64, 1), (128, 64, 1),
+                (64, 64, 1), (64, 64, 1))
 
 
 def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, accumulate=0):

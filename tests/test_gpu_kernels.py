@@ -149,7 +149,7 @@ def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
     assert rel_err(M.from_cl(gx32, N, T, Cin).cpu(), gx_ref.cpu()) < 3 * TOL["bf16"]
     # weight gradient: every (O x C) tile and several reduction splits, overwrite and accumulate modes
     gw_ref = gw_ref.permute(0, 2, 1) if spec.kind == "conv" else gw_ref.permute(1, 2, 0)        # -> [O, taps, I]
-    for tile in range(8):
+    for tile in range(len(ops._WGRAD_TILES)):
         for splits in (1, 3):
             for accumulate in (0, 1):
                 dW = torch.full((Co, k * Cin), 1.0 if accumulate else float("nan"), dtype=torch.float32, device=dev)
