@@ -136,10 +136,12 @@ int madiff_attn_bwd(int dtype, const void* qkv, int ldq, const void* dout, int l
 
 /* [B,T,A,F] fp32 -> [(b a), t, Fpad] storage type, optionally fused with add_noise (diffusers DDPMScheduler.add_noise,
  * called at models/diffusion.py:292) and inpainting (helpers.py:194-196, diffusion.py:293).  x_noisy (fp32, may be null)
- * receives the noised + inpainted trajectory in the reference layout. */
+ * receives the noised + inpainted trajectory in the reference layout.  x_ld: feature-row stride of x in elements (x may
+ * be the observation columns of the batch's [B,T,A,act+F] tensor, diffusion.py:463: `x[..., self.action_dim:]`, read in
+ * place); <= 0 means F. */
 int madiff_pack_input(int dtype, const float* x, const float* noise, const long* tsteps, const float* sqrt_ac,
                       const float* sqrt_1mac, const float* cond, const uint8_t* mask, void* out, float* x_noisy, int B,
-                      int T, int A, int F, int Fpad, madiff_stream_t stream);
+                      int T, int A, int F, int Fpad, int x_ld, madiff_stream_t stream);
 int madiff_unpack_output(int dtype, const void* in, int ld, float* out, int B, int T, int A, int F, madiff_stream_t stream);
 
 /* Fused posterior step: guidance blend eps_u + w (eps_c - eps_u) (diffusion.py:203-205), x0-predict, clip to [-1,1],
@@ -160,6 +162,31 @@ int madiff_mse_fwd(const float* pred, const float* targ, const float* w, const f
                    int F, madiff_stream_t stream);
 int madiff_mse_bwd(const float* pred, const float* targ, const float* w, const float* mask, const float* sums,
                    const float* go, float* dpred, int B, int TA, int F, madiff_stream_t stream);
+
+/* The whole training loss of GaussianDiffusion.loss (diffusion.py:438-496) in two launches: the masked weighted state loss
+ * (helpers.py:243-250, diffusion.py:328-330), the inverse-dynamics loss of compute_inv_loss (diffusion.py:369-436; shared or
+ * joint MLP; continuous MSE, or discrete cross-entropy over the legal actions with inv_acc) and 0.5 * (diffuse + inv)
+ * (diffusion.py:492).  masks [B,T,A] fp64 (masks_f64 != 0, as the dataset delivers them) or fp32; x [B,T,A,act+F] (actions
+ * first; discrete: column 0 = action id); legal [B,T,A,nout] or NULL; pred = output of the inverse-dynamics MLP, element
+ * (r = (b, t < T-1), a, o) at pred[r*pred_rs + a*pred_as + o].  mse_sums [B,3] is kept for backward.  workspace:
+ * madiff_loss_ws_doubles() doubles of scratch (partial sums between the two launches).  out / out_f [6] (double / float):
+ * {loss, a0_loss, inv_loss, inv_acc, sum of the inverse-dynamics masks, diffuse_loss}. */
+int madiff_loss_ws_doubles(void);
+int madiff_loss_fwd(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64, const float* pred,
+                    long pred_rs, long pred_as, const float* x, const float* legal, int B, int T, int A, int F, int act,
+                    int nout, int discrete, float* mse_sums, double* workspace, double* out, float* out_f,
+                    madiff_stream_t stream);
+/* Its backward in one launch: d_eps [B,T,A,F] and d_pred (layout of pred, pad columns zeroed) = *go times the gradient of
+ * `loss` (go: device scalar, fp64 when go_f64 != 0). */
+int madiff_loss_bwd(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64, const float* pred,
+                    long pred_rs, long pred_as, const float* x, const float* legal, int B, int T, int A, int F, int act,
+                    int nout, int discrete, const float* mse_sums, const double* out, const void* go, int go_f64,
+                    float* d_eps, float* d_pred, madiff_stream_t stream);
+/* Inputs of the inverse-dynamics MLP (diffusion.py:381-384): rows [o_t | o_{t+1}] for t < T-1 in the activation layout
+ * (storage type, ld columns, pad zeroed).  joint = 0: one row per (b, t, a); joint = 1: one row per (b, t), agents
+ * concatenated (joint_inv). */
+int madiff_inv_pairs(int dtype, const float* x, void* out, int ld, int B, int T, int A, int act, int F, int joint,
+                     madiff_stream_t stream);
 
 /* SinusoidalPosEmb (helpers.py:17-29) for timesteps ts[B], repeated over A agents: out [B*A, ld], cols >= 2*half zeroed. */
 int madiff_sinusoid(int dtype, const long* ts, const float* freq, void* out, int ld, int B, int A, int half,

@@ -13,7 +13,7 @@ __global__ void pack_input_kernel(const float* __restrict__ x, const float* __re
                                   const long* __restrict__ tsteps, const float* __restrict__ sqrt_ac,
                                   const float* __restrict__ sqrt_1mac, const float* __restrict__ cond,
                                   const uint8_t* __restrict__ mask, T* __restrict__ out, float* __restrict__ x_noisy,
-                                  int B, int Tn, int A, int F, int Fpad) {
+                                  int B, int Tn, int A, int F, int Fpad, int x_ld) {
   const long total = (long)B * A * Tn * Fpad;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     int f = e % Fpad;
@@ -25,7 +25,7 @@ __global__ void pack_input_kernel(const float* __restrict__ x, const float* __re
     float v = 0.f;
     if (f < F) {
       long src = (((long)b * Tn + t) * A + a) * F + f;
-      v = x[src];
+      v = x[(((long)b * Tn + t) * A + a) * x_ld + f];        // x may be a column slice of a wider [B,T,A,x_ld] tensor
       if (noise) {
         long ts = tsteps[b];
         v = sqrt_ac[ts] * v + sqrt_1mac[ts] * noise[src];
@@ -314,16 +314,17 @@ static inline int nblocks(long total, int per = 256, int cap = 4096) {
 
 extern "C" int madiff_pack_input(int dtype, const float* x, const float* noise, const long* tsteps, const float* sqrt_ac,
                                  const float* sqrt_1mac, const float* cond, const uint8_t* mask, void* out,
-                                 float* x_noisy, int B, int T, int A, int F, int Fpad, hipStream_t stream) {
+                                 float* x_noisy, int B, int T, int A, int F, int Fpad, int x_ld, hipStream_t stream) {
   if (B <= 0) return 0;
-  if (T <= 0 || A <= 0 || F <= 0 || Fpad < F || (noise && (!tsteps || !sqrt_ac || !sqrt_1mac)) || (mask && !cond)) return -1;
+  if (x_ld <= 0) x_ld = F;
+  if (T <= 0 || A <= 0 || F <= 0 || Fpad < F || x_ld < F || (noise && (!tsteps || !sqrt_ac || !sqrt_1mac)) || (mask && !cond)) return -1;
   long total = (long)B * A * T * Fpad;
   if (dtype == MADIFF_BF16)
     hipLaunchKernelGGL((pack_input_kernel<bf16_t>), dim3(nblocks(total)), dim3(256), 0, stream, x, noise, tsteps, sqrt_ac,
-                       sqrt_1mac, cond, mask, (bf16_t*)out, x_noisy, B, T, A, F, Fpad);
+                       sqrt_1mac, cond, mask, (bf16_t*)out, x_noisy, B, T, A, F, Fpad, x_ld);
   else
     hipLaunchKernelGGL((pack_input_kernel<float>), dim3(nblocks(total)), dim3(256), 0, stream, x, noise, tsteps, sqrt_ac,
-                       sqrt_1mac, cond, mask, (float*)out, x_noisy, B, T, A, F, Fpad);
+                       sqrt_1mac, cond, mask, (float*)out, x_noisy, B, T, A, F, Fpad, x_ld);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

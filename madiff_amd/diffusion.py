@@ -57,6 +57,12 @@ class InvDynMLP(nn.Sequential):
         self.out_dim = out_dim
         self.softmax = softmax
 
+    def logits_cl(self, h):
+        """cl rows [R, pad32(in_dim)] -> fp32 [R, pad32(out_dim)] (no softmax): the fused loss reads this directly."""
+        h = conv_gemm(h, [self[0].weight], [self[0].bias], LINEAR, 1, act=1)
+        h = conv_gemm(h, [self[2].weight], [self[2].bias], LINEAR, 1, act=1)
+        return conv_gemm(h, [self[4].weight], [self[4].bias], LINEAR, 1, perm="f32")
+
     def forward(self, x):
         lead = x.shape[:-1]
         h = rows_to_cl(x.reshape(-1, x.shape[-1]).to(torch.float32))
@@ -69,6 +75,7 @@ class InvDynMLP(nn.Sequential):
 
 
 INV_SIDE_STREAM = os.environ.get("MADIFF_INV_SIDE_STREAM", "1") != "0"
+FUSED_LOSS = os.environ.get("MADIFF_FUSED_LOSS", "1") != "0"
 # GaussianDiffusion -> its captured denoising step (kept outside the module: deepcopy / pickling of the module stay plain)
 _SAMPLE_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
@@ -298,16 +305,18 @@ class GaussianDiffusion(nn.Module):
     p_sample_loop = conditional_sample
 
     # ------------------------------------------------------------------ training
-    def p_losses(self, x_start, cond, t, loss_masks, attention_masks=None, returns=None, env_ts=None, states=None,
-                 noise=None, dropout_mask=None):
-        """diffusion.py:279-337.  add_noise + inpainting + layout change are one kernel; the masked weighted MSE
-        and its gradient are one kernel each."""
+    def _predict_noise(self, x_start, cond, t, returns=None, env_ts=None, noise=None, dropout_mask=None):
+        """diffusion.py:290-302: draw the noise, add_noise + inpainting + layout change (one kernel), denoiser forward.
+        -> (epsilon [B,T,A,F] fp32, noise)."""
         if noise is None:
-            noise = torch.randn_like(x_start)
+            noise = torch.randn(x_start.shape, dtype=x_start.dtype, device=x_start.device)
         device = x_start.device
         tb = self._sched_tables(self.noise_scheduler, device)
         B, T, A, Fd = x_start.shape
-        mask = cond["masks"].to(device=device, dtype=torch.uint8).contiguous()
+        mask = cond["masks"]
+        if mask.dtype != torch.uint8:
+            mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        mask = mask.to(device).contiguous()
         xcl = ops.pack_traj(x_start.to(torch.float32), pad32(Fd), noise=noise.contiguous(), t=t.contiguous(),
                             sqrt_ac=tb["sqrt_ac"], sqrt_1mac=tb["sqrt_1mac"],
                             cond=cond["x"].to(device, torch.float32).contiguous(), mask=mask)
@@ -315,6 +324,15 @@ class GaussianDiffusion(nn.Module):
                                     dropout_mask, env_ts)
         epsilon = self.model.forward_cl(xcl, B, T, temb)
         assert noise.shape == epsilon.shape
+        return epsilon, noise
+
+    def p_losses(self, x_start, cond, t, loss_masks, attention_masks=None, returns=None, env_ts=None, states=None,
+                 noise=None, dropout_mask=None):
+        """diffusion.py:279-337.  add_noise + inpainting + layout change are one kernel; the masked weighted MSE
+        and its gradient are one kernel each."""
+        epsilon, noise = self._predict_noise(x_start, cond, t, returns, env_ts, noise, dropout_mask)
+        B, T, A, Fd = x_start.shape
+        device = x_start.device
         m32 = loss_masks.to(device=device, dtype=torch.float32).reshape(B, T, A).contiguous()
         loss, a0 = MaskedStateLoss.apply(epsilon, noise, self.loss_fn.weights.contiguous(), m32)
         if loss_masks.dtype != torch.float64:
@@ -362,9 +380,13 @@ class GaussianDiffusion(nn.Module):
     def loss(self, x, cond, loss_masks, attention_masks=None, returns=None, env_ts=None, states=None,
              legal_actions=None, t=None, noise=None, dropout_mask=None):
         """diffusion.py:438-496; called as ``loss(**batch)``."""
-        # The inverse-dynamics branch shares nothing with the denoiser branch until the final sum, and it is ~50 small
-        # launches: on the GPU it runs on a second stream (forward here, backward there too, since autograd replays
+        # The inverse-dynamics branch shares nothing with the denoiser branch until the final sum, and it is a chain of
+        # small launches: on the GPU it runs on a second stream (forward here, backward there too, since autograd replays
         # a node on its forward stream), i.e. as a parallel branch of the captured train-step graph.
+        fused = (x.is_cuda and FUSED_LOSS and not self.train_only_inv and (self.share_inv or self.joint_inv)
+                 and x.dtype == torch.float32 and loss_masks.dtype in (torch.float32, torch.float64))
+        if fused:
+            return self._loss_fused(x, cond, loss_masks, returns, env_ts, legal_actions, t, noise, dropout_mask)
         side = None
         if x.is_cuda and not self.train_only_inv and INV_SIDE_STREAM:
             cur = torch.cuda.current_stream()
@@ -393,6 +415,32 @@ class GaussianDiffusion(nn.Module):
         if self.train_only_inv:
             return inv_loss, info
         return (1 / 2) * (diffuse_loss + inv_loss), info
+
+    def _loss_fused(self, x, cond, loss_masks, returns, env_ts, legal_actions, t, noise, dropout_mask):
+        """loss() for the shared / joint inverse-dynamics head on the GPU: the MLP's inputs come straight from the batch
+        tensor (madiff_inv_pairs), its logits and the denoiser's epsilon go into ONE loss node (ops.FusedLoss: two launches
+        forward, one backward) -- no ATen kernel between the two networks and the scalar loss."""
+        B, T, A, _ = x.shape
+        x = x.contiguous()
+        nout = self.num_actions if self.discrete_action else self.action_dim
+        cur = torch.cuda.current_stream()
+        side = ops.aux_stream(x.device) if INV_SIDE_STREAM else cur
+        ops.wait_stream(side, cur)
+        with torch.cuda.stream(side):
+            logits = self.inv_model.logits_cl(ops.inv_pairs(x, self.action_dim, self.joint_inv))
+        if t is None:
+            t = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (B,), device=x.device).long()
+        epsilon, noise = self._predict_noise(x[..., self.action_dim:], cond, t, returns, env_ts, noise, dropout_mask)
+        ops.wait_stream(cur, side)
+        logits.record_stream(cur)
+        loss, a0, inv_loss, inv_acc = ops.FusedLoss.apply(
+            epsilon, noise, self.loss_fn.weights, loss_masks.reshape(B, T, A), logits, x, legal_actions,
+            (self.action_dim, nout, self.discrete_action, self.joint_inv))
+        info = {"a0_loss": a0}
+        if self.discrete_action:
+            info["inv_acc"] = inv_acc
+        info["inv_loss"] = inv_loss
+        return loss, info
 
     def forward(self, cond, *args, **kwargs):
         return self.conditional_sample(cond=cond, *args, **kwargs)

@@ -40,7 +40,12 @@ _SIGS = {
     "madiff_gn_mish_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_attn_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_attn_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "madiff_pack_input": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "madiff_pack_input": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "madiff_loss_ws_doubles": [],
+    "madiff_loss_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "madiff_loss_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp,
+                        _vp],
+    "madiff_inv_pairs": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_unpack_output": [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "madiff_posterior_step": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp],
     "madiff_inpaint": [_vp, _vp, _vp, _l, _vp],

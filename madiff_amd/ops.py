@@ -545,13 +545,17 @@ def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, acc
 
 def pack_traj(x: torch.Tensor, fpad: int, noise=None, t=None, sqrt_ac=None, sqrt_1mac=None, cond=None, mask=None,
               x_noisy=None) -> torch.Tensor:
-    """[B,T,A,F] fp32 -> cl [(b a) t, fpad] (optionally fused add_noise + inpainting)."""
+    """[B,T,A,F] fp32 -> cl [(b a) t, fpad] (optionally fused add_noise + inpainting).  x may be a column slice of a wider
+    contiguous [B,T,A,W] tensor (the batch's observation columns, diffusion.py:463): it is read in place."""
     B, T, A, F = x.shape
-    x = x.contiguous()
     assert x.dtype == torch.float32
+    W = x.stride(2)
+    if not (x.stride(3) == 1 and W >= F and x.stride(1) == A * W and x.stride(0) == T * A * W):
+        x = x.contiguous()
+        W = F
     out = torch.empty(B * A * T, fpad, dtype=act_dtype(), device=x.device)
     lib.call("madiff_pack_input", _dt(), x.data_ptr(), _p(noise), _p(t), _p(sqrt_ac), _p(sqrt_1mac), _p(cond), _p(mask),
-             out.data_ptr(), _p(x_noisy), B, T, A, F, fpad, _stream())
+             out.data_ptr(), _p(x_noisy), B, T, A, F, fpad, W, _stream())
     return out
 
 
@@ -1239,6 +1243,76 @@ class MaskedStateLoss(torch.autograd.Function):
         lib.call("madiff_mse_bwd", pred.data_ptr(), targ.data_ptr(), w.data_ptr(), mask.data_ptr(), sums.data_ptr(),
                  go.data_ptr(), dp.data_ptr(), B, T * A, F, _stream())
         return dp, None, None, None
+
+
+def inv_pairs(x: torch.Tensor, act: int, joint: bool) -> torch.Tensor:
+    """Inputs of the inverse-dynamics MLP, [o_t | o_{t+1}] for t < T-1 (diffusion.py:381-384), straight from the batch's
+    x [B,T,A,act+F] into the GEMM's activation layout: cl [B(T-1)A, pad32(2F)], or [B(T-1), pad32(A 2F)] for joint_inv."""
+    B, T, A, W = x.shape
+    F = W - act
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    rows, ld = (B * (T - 1), pad32(A * 2 * F)) if joint else (B * (T - 1) * A, pad32(2 * F))
+    out = torch.empty(rows, ld, dtype=act_dtype(), device=x.device)
+    lib.call("madiff_inv_pairs", _dt(), x.data_ptr(), out.data_ptr(), ld, B, T, A, act, F, int(joint), _stream())
+    return out
+
+
+class FusedLoss(torch.autograd.Function):
+    """GaussianDiffusion.loss after the two networks have run (diffusion.py:311,328-330,369-436,492): masked weighted
+    state loss + inverse-dynamics loss (shared / joint MLP; MSE or legal-action cross-entropy + inv_acc) + 0.5 * sum, two
+    launches forward and one backward.
+
+    apply(eps [B,T,A,F], noise, w [T,A,F], loss_masks [B,T,A(,1)] fp64|fp32, pred fp32 [rows, ld], x [B,T,A,act+F],
+          legal [B,T,A,nout] | None, (act, nout, discrete, joint)) -> (loss, a0_loss, inv_loss, inv_acc)
+    loss / inv_loss / inv_acc take the dtype of loss_masks (the reference's promotion), a0_loss is fp32."""
+
+    @staticmethod
+    def forward(ctx, eps, noise, w, masks, pred, x, legal, geom):
+        act, nout, discrete, joint = geom
+        B, T, A, F = eps.shape
+        eps, noise, w, pred, x = eps.contiguous(), noise.contiguous(), w.contiguous(), pred.contiguous(), x.contiguous()
+        masks = masks.contiguous()
+        assert masks.dtype in (torch.float64, torch.float32) and masks.numel() == B * T * A
+        assert eps.dtype == noise.dtype == pred.dtype == x.dtype == torch.float32 and x.shape == (B, T, A, act + F)
+        if legal is not None:
+            legal = legal.to(torch.float32).contiguous()
+            assert legal.shape == (B, T, A, nout)
+        ld = pred.shape[1]
+        if joint:
+            assert pred.shape[0] == B * (T - 1) and ld >= A * nout
+            rs, as_ = ld, nout
+        else:
+            assert pred.shape[0] == B * (T - 1) * A and ld >= nout
+            rs, as_ = A * ld, ld
+        dev = eps.device
+        sums = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib._lib.madiff_loss_ws_doubles(), dtype=torch.float64, device=dev)
+        out = torch.empty(6, dtype=torch.float64, device=dev)
+        out_f = torch.empty(6, dtype=torch.float32, device=dev)
+        f64 = masks.dtype == torch.float64
+        lib.call("madiff_loss_fwd", eps.data_ptr(), noise.data_ptr(), w.data_ptr(), masks.data_ptr(), int(f64), pred.data_ptr(),
+                 rs, as_, x.data_ptr(), _p(legal), B, T, A, F, act, nout, int(discrete), sums.data_ptr(), ws.data_ptr(),
+                 out.data_ptr(), out_f.data_ptr(), _stream())
+        ctx.save_for_backward(eps, noise, w, masks, pred, x, legal, sums, out)
+        ctx.geom = (B, T, A, F, act, nout, int(discrete), rs, as_, int(f64))
+        o = out if f64 else out_f
+        res = (o[0], out_f[1], o[2], o[3])
+        ctx.mark_non_differentiable(*res[1:])
+        return res
+
+    @staticmethod
+    def backward(ctx, gl, *_unused):
+        eps, noise, w, masks, pred, x, legal, sums, out = ctx.saved_tensors
+        B, T, A, F, act, nout, discrete, rs, as_, f64 = ctx.geom
+        if gl.dtype not in (torch.float32, torch.float64):
+            gl = gl.to(torch.float32)
+        gl = gl.contiguous()
+        d_eps = torch.empty_like(eps)
+        d_pred = torch.empty_like(pred)
+        lib.call("madiff_loss_bwd", eps.data_ptr(), noise.data_ptr(), w.data_ptr(), masks.data_ptr(), f64, pred.data_ptr(),
+                 rs, as_, x.data_ptr(), _p(legal), B, T, A, F, act, nout, discrete, sums.data_ptr(), out.data_ptr(),
+                 gl.data_ptr(), int(gl.dtype == torch.float64), d_eps.data_ptr(), d_pred.data_ptr(), _stream())
+        return d_eps, None, None, None, d_pred, None, None, None
 
 
 def posterior_step(x, eps_c, eps_u, w, z, cond, mask_u8, coef, out, step_ptr=None, step_val=0):
