@@ -176,6 +176,18 @@ int madiff_loss_fwd(const float* eps, const float* noise, const float* w, const 
                     long pred_rs, long pred_as, const float* x, const float* legal, int B, int T, int A, int F, int act,
                     int nout, int discrete, float* mse_sums, double* workspace, double* out, float* out_f,
                     madiff_stream_t stream);
+/* madiff_loss_fwd for callers that cannot allocate (no counterpart in the reference; for code under hipGraph capture
+ * without a memory pool, serving loops and harnesses that forbid hipMalloc): same inputs and outputs, but no workspace and no
+ * mse_sums argument -- both live in a fixed device array inside the library (193.5 KB per GPU, held until the process ends),
+ * and neither this call nor anything it calls allocates or frees.  Forward only (loss evaluation / logging).  Limit:
+ * B <= 16384; beyond it the call launches nothing and returns -2.  Calls that overlap on one GPU share the array and
+ * race; calls on one stream are ordered.  madiff_loss_static_init() resolves the array's device address for the current
+ * GPU (hipGetSymbolAddress); the entry point does the same on its first call on a device, so the init call is only needed
+ * where even that must happen at set-up time (e.g. before a capture). */
+int madiff_loss_static_init(void);
+int madiff_loss_fwd_static(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64,
+                           const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B, int T,
+                           int A, int F, int act, int nout, int discrete, double* out, float* out_f, madiff_stream_t stream);
 /* Its backward in one launch: d_eps [B,T,A,F] and d_pred (layout of pred, pad columns zeroed) = *go times the gradient of
  * `loss` (go: device scalar, fp64 when go_f64 != 0). */
 int madiff_loss_bwd(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64, const float* pred,

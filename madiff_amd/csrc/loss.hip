@@ -238,6 +238,51 @@ extern "C" int madiff_loss_fwd(const float* eps, const float* noise, const float
   return loss_fwd_impl(p, mse_sums, workspace, out, out_f, stream);
 }
 
+// ---- the same forward with NO workspace argument and no allocation anywhere: for callers that cannot allocate (code under
+// hipGraph capture without a private pool, serving loops and harnesses that forbid hipMalloc).  The scratch -- the partial
+// sums between the two launches and the per-sample sums [B,3] that madiff_loss_fwd hands back for its backward -- lives in a
+// file-scope device array of fixed size, one copy per GPU, held until the process ends.  Forward only (loss evaluation /
+// logging): the per-sample sums stay inside the library.  Every call on a GPU uses that GPU's one array: calls that overlap on
+// one GPU (two streams, two threads) race; calls on one stream are ordered.  Nothing in it has to start at zero: both
+// launches overwrite every element they later read.
+#define MADIFF_LOSS_STATIC_MAX_B 16384
+#define MADIFF_LOSS_STATIC_BYTES (MADIFF_LOSS_WS_DOUBLES * 8 + MADIFF_LOSS_STATIC_MAX_B * 3 * 4)
+static __device__ __align__(256) unsigned char scratch[MADIFF_LOSS_STATIC_BYTES];   // 1.5 KB + 192 KB per GPU
+#define MADIFF_MAX_DEVICES 64
+static void* g_scratch_ptr[MADIFF_MAX_DEVICES];   // device address of `scratch` on each GPU (the array's name is a host-side stand-in)
+
+extern "C" int madiff_loss_static_init(void) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= MADIFF_MAX_DEVICES) return -1;
+  if (g_scratch_ptr[dev]) return 0;
+  void* ptr = nullptr;
+  e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+  if (e != hipSuccess) return (int)e;
+  if (!ptr) return -1;
+  g_scratch_ptr[dev] = ptr;
+  return 0;
+}
+
+extern "C" int madiff_loss_fwd_static(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64,
+                                      const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B,
+                                      int T, int A, int F, int act, int nout, int discrete, double* out, float* out_f,
+                                      hipStream_t stream) {
+  LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete};
+  if (loss_check(p) || !out || !out_f) return -1;
+  if (B > MADIFF_LOSS_STATIC_MAX_B) return -2;            // beyond the static scratch: use madiff_loss_fwd with a workspace
+  int rc = madiff_loss_static_init();                     // (first call on this device; a no-op afterwards)
+  if (rc) return rc;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  unsigned char* base = (unsigned char*)g_scratch_ptr[dev];
+  double* ws = (double*)base;
+  float* mse_sums = (float*)(base + MADIFF_LOSS_WS_DOUBLES * 8);
+  return loss_fwd_impl(p, mse_sums, ws, out, out_f, stream);
+}
+
 extern "C" int madiff_loss_bwd(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64,
                                const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B, int T,
                                int A, int F, int act, int nout, int discrete, const float* mse_sums, const double* out,

@@ -43,6 +43,8 @@ _SIGS = {
     "madiff_pack_input": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_loss_ws_doubles": [],
     "madiff_loss_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "madiff_loss_static_init": [],
+    "madiff_loss_fwd_static": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "madiff_loss_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp,
                         _vp],
     "madiff_inv_pairs": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
