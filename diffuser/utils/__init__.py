@@ -1,4 +1,4 @@
-from madiff_amd.diffusion import Encoder, IdentityEncoder  # noqa: F401
+from madiff_amd.diffusion import Encoder, IdentityEncoder, SMAC3mEncoder, SMAC5m6mEncoder  # noqa: F401
 from madiff_amd.host import (  # noqa: F401
     Config,
     Progress,

@@ -152,6 +152,9 @@ int madiff_posterior_step(const float* x, const float* eps_c, const float* eps_u
                           const uint8_t* mask, const float* coef, const int* step_ptr, int step_val, float* out, long total,
                           madiff_stream_t stream);
 int madiff_inpaint(float* x, const float* cond, const uint8_t* mask, long total, madiff_stream_t stream);
+/* The SMAC data encoders (utils/data_encoder.py:11-20), applied where the reference calls self.data_encoder
+ * (diffusion.py:252,269,294): x[b, t >= 1, a, f < k] = x[b, 0, a, f], in place on a [B,T,A,F] fp32 trajectory. */
+int madiff_encode_first_k(float* x, int B, int T, int A, int F, int k, madiff_stream_t stream);
 /* Device-side step counter of the captured sampling loop (replaces the host loop variable of diffusion.py:249-255). */
 int madiff_sampler_fill_time(const int* state, const long* tsteps, long* ts_out, int B, madiff_stream_t stream);
 int madiff_sampler_advance(int* state, madiff_stream_t stream);

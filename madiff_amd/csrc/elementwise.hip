@@ -83,6 +83,21 @@ __global__ void inpaint_kernel(float* __restrict__ x, const float* __restrict__ 
     if (mask[e]) x[e] = cond[e];
 }
 
+// SMAC data encoders (utils/data_encoder.py:11-20: `data[..., 1:, :, :k] = data[..., 0:1, :, :k]`): the first k features of
+// every later time step take the value of time step 0.  In place: the entries read (t = 0) are never written.
+__global__ void encode_first_k_kernel(float* __restrict__ x, int B, int Tn, int A, int F, int k) {
+  const long total = (long)B * (Tn - 1) * A * k;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int f = (int)(e % k);
+    long r = e / k;
+    const int a = (int)(r % A);
+    r /= A;
+    const int t = 1 + (int)(r % (Tn - 1));
+    const long b = r / (Tn - 1);
+    x[((b * Tn + t) * A + a) * F + f] = x[((b * Tn) * A + a) * F + f];
+  }
+}
+
 // sampler state: state[0] = step index.  fill: ts_out[b] = tsteps[state[0]]; advance: state[0] += 1.
 __global__ void sampler_fill_time_kernel(const int* __restrict__ state, const long* __restrict__ tsteps,
                                          long* __restrict__ ts_out, int B) {
@@ -357,6 +372,14 @@ extern "C" int madiff_inpaint(float* x, const float* cond, const uint8_t* mask, 
   if (total <= 0) return 0;
   if (!x || !cond || !mask) return -1;
   hipLaunchKernelGGL(inpaint_kernel, dim3(nblocks(total)), dim3(256), 0, stream, x, cond, mask, total);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int madiff_encode_first_k(float* x, int B, int T, int A, int F, int k, hipStream_t stream) {
+  if (B <= 0 || T <= 1 || k <= 0) return 0;
+  if (!x || A <= 0 || F <= 0 || k > F) return -1;
+  hipLaunchKernelGGL(encode_first_k_kernel, dim3(nblocks((long)B * (T - 1) * A * k)), dim3(256), 0, stream, x, B, T, A, F, k);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from .modules import rows_to_cl
+from .modules import SharedConvAttentionDeconv, rows_to_cl
 from .ops import LINEAR, MaskedStateLoss, conv_gemm, pad32
 from .schedulers import DDIMScheduler, DDPMScheduler
 
@@ -39,6 +39,27 @@ class IdentityEncoder(Encoder):
 
     def __call__(self, data):
         return data
+
+
+class _FirstKEncoder(Encoder):
+    """utils/data_encoder.py:11-20: the first k observation features (the agent's own unit features in SMAC) of every
+    later time step are overwritten by those of time step 0.  Callable on any [..., T, A, F] tensor like the reference's
+    (in place); GaussianDiffusion applies it with one HIP launch (madiff_encode_first_k)."""
+
+    first_k = 0
+
+    def __call__(self, data):
+        k = self.first_k
+        data[..., 1:, :, :k] = data[..., 0:1, :, :k]
+        return data
+
+
+class SMAC5m6mEncoder(_FirstKEncoder):
+    first_k = 5
+
+
+class SMAC3mEncoder(_FirstKEncoder):
+    first_k = 3
 
 
 class InvDynMLP(nn.Sequential):
@@ -189,8 +210,14 @@ class GaussianDiffusion(nn.Module):
         """Guided epsilon (diffusion.py:176-212); the blend itself is fused into the posterior kernel during
         sampling, this entry point returns the blended tensor for callers that want it."""
         if self.returns_condition:
-            ec, eu = self.model.forward_guided_pair(ops.pack_traj(x.contiguous(), pad32(x.shape[-1])), x.shape[0],
-                                                    x.shape[1], t, returns, env_ts)
+            if isinstance(self.model, SharedConvAttentionDeconv):
+                ec, eu = self.model.forward_guided_pair(ops.pack_traj(x.contiguous(), pad32(x.shape[-1])), x.shape[0],
+                                                        x.shape[1], t, returns, env_ts)
+            else:
+                ec = self.model(x, t, returns=returns, env_timestep=env_ts, attention_masks=attention_masks,
+                                use_dropout=False)
+                eu = self.model(x, t, returns=returns, env_timestep=env_ts, attention_masks=attention_masks,
+                                use_dropout=False, force_dropout=True)
             return eu + self.condition_guidance_w * (ec - eu)
         return self.model(x, t, env_timestep=env_ts, attention_masks=attention_masks)
 
@@ -201,12 +228,22 @@ class GaussianDiffusion(nn.Module):
         lib = ops.lib
         lib.call("madiff_sampler_fill_time", st["state"].data_ptr(), st["tsteps"].data_ptr(), st["ts"].data_ptr(), bsz,
                  ops._stream())
-        xcl = ops.pack_traj(x, pad32(x.shape[-1]))
-        if self.returns_condition:
-            ec, eu = self.model.forward_guided_pair(xcl, bsz, t_len, st["ts"], returns, env_ts)
+        x = self._encode_(x)                                # diffusion.py:252 (x arrives inpainted)
+        if isinstance(self.model, SharedConvAttentionDeconv):
+            xcl = ops.pack_traj(x, pad32(x.shape[-1]))
+            if self.returns_condition:
+                ec, eu = self.model.forward_guided_pair(xcl, bsz, t_len, st["ts"], returns, env_ts)
+            else:
+                temb = self.model.net.embed(st["ts"], None, self.n_agents, False, False, None, env_ts)
+                ec, eu = self.model.forward_cl(xcl, bsz, t_len, temb), None
+        elif self.returns_condition:                        # any other denoiser: two passes (diffusion.py:187-202)
+            ec = self.model(x, st["ts"], returns=returns, env_timestep=env_ts, attention_masks=None, use_dropout=False)
+            # use_dropout=False: the reference's Bernoulli draw here is multiplied by zero (temporal.py:377-381), and a
+            # host-side draw cannot be captured into the sampling graph
+            eu = self.model(x, st["ts"], returns=returns, env_timestep=env_ts, attention_masks=None, use_dropout=False,
+                            force_dropout=True)
         else:
-            temb = self.model.net.embed(st["ts"], None, self.n_agents, False, False, None, env_ts)
-            ec, eu = self.model.forward_cl(xcl, bsz, t_len, temb), None
+            ec, eu = self.model(x, st["ts"], env_timestep=env_ts, attention_masks=None), None
         z = st["z"]
         ops.posterior_step(x, ec.contiguous(), None if eu is None else eu.contiguous(), self.condition_guidance_w, z,
                            st["cond_x"], st["mask"], st["coef"], x, step_ptr=st["state"])
@@ -227,8 +264,6 @@ class GaussianDiffusion(nn.Module):
         sched = self.ddim_noise_scheduler if self.use_ddim_sample else self.noise_scheduler
         tb = self._sched_tables(sched, device)
         n_steps = tb["timesteps"].shape[0]
-        if not isinstance(self.data_encoder, IdentityEncoder):
-            raise NotImplementedError("non-identity data encoders are outside the hot path (SURVEY.md 8f F4)")
         if use_graph is None:
             use_graph = not return_diffusion
 
@@ -297,7 +332,8 @@ class GaussianDiffusion(nn.Module):
             if return_diffusion:
                 chain.append(st["x"].clone())
         x = st["x"].clone() if graph is not None else st["x"]     # (the persistent buffer is reused by the next call)
-        # the posterior kernel already enforced the final conditioning (diffusion.py:268)
+        # the posterior kernel already enforced the final conditioning (diffusion.py:268); then the encoder (:269)
+        x = self._encode_(x)
         if return_diffusion:
             return x, torch.stack(chain, dim=1)
         return x
@@ -317,14 +353,36 @@ class GaussianDiffusion(nn.Module):
         if mask.dtype != torch.uint8:
             mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
         mask = mask.to(device).contiguous()
+        identity = isinstance(self.data_encoder, IdentityEncoder)
+        fast = isinstance(self.model, SharedConvAttentionDeconv)
+        x_noisy = None if (identity and fast) else torch.empty(B, T, A, Fd, dtype=torch.float32, device=device)
         xcl = ops.pack_traj(x_start.to(torch.float32), pad32(Fd), noise=noise.contiguous(), t=t.contiguous(),
                             sqrt_ac=tb["sqrt_ac"], sqrt_1mac=tb["sqrt_1mac"],
-                            cond=cond["x"].to(device, torch.float32).contiguous(), mask=mask)
-        temb = self.model.net.embed(t, returns if self.model.returns_condition else None, A, True, False,
-                                    dropout_mask, env_ts)
-        epsilon = self.model.forward_cl(xcl, B, T, temb)
+                            cond=cond["x"].to(device, torch.float32).contiguous(), mask=mask, x_noisy=x_noisy)
+        if not identity:                       # diffusion.py:294 (after the conditioning)
+            x_noisy = self._encode_(x_noisy)
+            xcl = ops.pack_traj(x_noisy, pad32(Fd)) if fast else None
+        if fast:
+            temb = self.model.net.embed(t, returns if self.model.returns_condition else None, A, True, False,
+                                        dropout_mask, env_ts)
+            epsilon = self.model.forward_cl(xcl, B, T, temb)
+        else:                                  # any other denoiser with the reference's call surface (the wrappers)
+            kw = {} if dropout_mask is None else {"dropout_mask": dropout_mask}
+            epsilon = self.model(x_noisy, t, returns=returns, env_timestep=env_ts, attention_masks=None, **kw)
         assert noise.shape == epsilon.shape
         return epsilon, noise
+
+    def _encode_(self, x):
+        """self.data_encoder applied to a [B,T,A,F] fp32 trajectory, in place where the encoder allows it."""
+        enc = self.data_encoder
+        if isinstance(enc, IdentityEncoder):
+            return x
+        k = getattr(enc, "first_k", None)
+        if k is not None and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32:
+            B, T, A, Fd = x.shape
+            ops.lib.call("madiff_encode_first_k", x.data_ptr(), B, T, A, Fd, int(k), ops._stream())
+            return x
+        return enc(x)
 
     def p_losses(self, x_start, cond, t, loss_masks, attention_masks=None, returns=None, env_ts=None, states=None,
                  noise=None, dropout_mask=None):

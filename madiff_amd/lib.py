@@ -51,6 +51,7 @@ _SIGS = {
     "madiff_unpack_output": [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "madiff_posterior_step": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp],
     "madiff_inpaint": [_vp, _vp, _vp, _l, _vp],
+    "madiff_encode_first_k": [_vp, _i, _i, _i, _i, _i, _vp],
     "madiff_sampler_fill_time": [_vp, _vp, _vp, _i, _vp],
     "madiff_sampler_advance": [_vp, _vp],
     "madiff_mse_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

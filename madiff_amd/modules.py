@@ -207,6 +207,39 @@ class TemporalSelfAttention(nn.Module):
         return from_cl(y, b * a, t, c).reshape(b, a, c, t)
 
 
+class SelfAttention(nn.Module):
+    """helpers.py:77-124: the cross-agent attention without timestep conditioning (same fused Q/K/V GEMM and attention
+    kernel as TemporalSelfAttention, no time row-bias).  In the reference only ConvAttentionDeconv and the value networks
+    build it -- classes whose constructors raise -- so it is provided as a module."""
+
+    def __init__(self, n_channels: int, qk_n_channels: int, v_n_channels: int, nheads: int = 4, residual: bool = False):
+        super().__init__()
+        self.nheads = nheads
+        self.query_layer = nn.Conv1d(n_channels, qk_n_channels * nheads, kernel_size=1)
+        self.key_layer = nn.Conv1d(n_channels, qk_n_channels * nheads, kernel_size=1)
+        self.value_layer = nn.Conv1d(n_channels, v_n_channels * nheads, kernel_size=1)
+        self.attend = _Tag()
+        self.residual = residual
+        if residual:
+            self.gamma = nn.Parameter(torch.zeros([1]))
+        self.n_channels = n_channels
+        self.cq = qk_n_channels * nheads
+        self.cv = v_n_channels * nheads
+        if self.cv != n_channels:
+            raise NotImplementedError("value width must equal the channel count (out.reshape(x.shape), helpers.py:121)")
+
+    def forward_cl(self, x, bsz, n_agents, t):
+        qkv = conv_gemm(x, [self.query_layer.weight, self.key_layer.weight, self.value_layer.weight],
+                        [self.query_layer.bias, self.key_layer.bias, self.value_layer.bias], CONV1, t)
+        return AttnCore.apply(qkv, x, self.gamma if self.residual else None, bsz, n_agents, t, self.nheads, self.cq,
+                              self.n_channels, self.residual)
+
+    def forward(self, x, states=None):
+        b, a, c, t = x.shape
+        y = self.forward_cl(to_cl(x.reshape(b * a, c, t)), b, a, t)
+        return from_cl(y, b * a, t, c).reshape(b, a, c, t)
+
+
 class TemporalUnet(nn.Module):
     """temporal.py:203-346 (constructor = parameter layout).  Its forward is only used for a single agent
     group; SharedConvAttentionDeconv drives the blocks itself."""
@@ -297,10 +330,57 @@ class TemporalUnet(nn.Module):
             t = torch.nn.functional.pad(t, (0, pad32(t.shape[1]) - t.shape[1]))
         return t.contiguous()
 
+    def rtb_blocks(self):
+        """The residual blocks in execution order (their Linear(Mish(t_emb)) run as one GEMM per forward)."""
+        blocks: List[ResidualTemporalBlock] = []
+        for r1, r2, _ in self.downs:
+            blocks += [r1, r2]
+        blocks += [self.mid_block1, self.mid_block2]
+        for r1, r2, _ in self.ups:
+            blocks += [r1, r2]
+        return blocks
+
+    def forward_cl(self, xcl, n_seq, t_len, temb):
+        """The U-Net alone on n_seq independent sequences (temporal.py:390-406): xcl cl [n_seq*t, pad32(F)], temb cl
+        [n_seq, pad32(E)] -> fp32 [n_seq, T, F]."""
+        blocks = self.rtb_blocks()
+        layers = [b.time_mlp[1] for b in blocks]
+        proj_all = conv_gemm(mish(temb), [l.weight for l in layers], [l.bias for l in layers], LINEAR, 1, perm="f32")
+        bproj = list(ops.SplitCols.apply(proj_all, tuple(b.out_channels for b in blocks)))
+        bi = 0
+        h, t = xcl, t_len
+        skips = []
+        for r1, r2, down in self.downs:
+            h = r1.forward_cl(h, t, bproj[bi]); bi += 1
+            h = r2.forward_cl(h, t, bproj[bi]); bi += 1
+            skips.append((h, t))
+            if isinstance(down, Downsample1d):
+                h, t = down.forward_cl(h, t)
+        h = self.mid_block1.forward_cl(h, t, bproj[bi]); bi += 1
+        h = self.mid_block2.forward_cl(h, t, bproj[bi]); bi += 1
+        for r1, r2, up in self.ups:
+            s, ts = skips.pop()
+            assert ts == t, "skip/upsample length mismatch (horizon must be divisible by 2**(levels-1))"
+            h = r1.forward_cl(h, t, bproj[bi], x2=s); bi += 1
+            h = r2.forward_cl(h, t, bproj[bi]); bi += 1
+            if isinstance(up, Upsample1d):
+                h, t = up.forward_cl(h, t)
+        h = self.final_conv[0].forward_cl(h, t)
+        fc = self.final_conv[1]
+        out = conv_gemm(h, [fc.weight], [fc.bias], CONV1, t, perm=(t, 1))
+        return out.reshape(n_seq, t, self.transition_dim)
+
     def forward(self, x, time, returns=None, env_timestep=None, attention_masks=None, use_dropout=True,
-                force_dropout=False):
-        raise NotImplementedError("single-agent TemporalUnet.forward is outside the MADiff hot path "
-                                  "(every exp_spec selects SharedConvAttentionDeconv)")
+                force_dropout=False, dropout_mask=None):
+        """temporal.py:348-406.  x : [ batch x horizon x transition ];  returns : [ batch x 1 ].  dropout_mask (optional,
+        [batch, 1]): the explicit Bernoulli draw of the use_dropout branch (otherwise drawn like the reference)."""
+        bsz, t_len = x.shape[0], x.shape[1]
+        if self.returns_condition and use_dropout and dropout_mask is None:
+            dropout_mask = self.mask_dist.sample(sample_shape=(bsz, 1))
+        temb = self.embed(time, None if returns is None else returns.reshape(bsz, 1, 1), 1, use_dropout, force_dropout,
+                          None if dropout_mask is None else dropout_mask.reshape(bsz, 1, 1), env_timestep)
+        xcl = PackTraj.apply(x.to(torch.float32).unsqueeze(2))
+        return self.forward_cl(xcl, bsz, t_len, temb)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -318,9 +398,13 @@ class SharedConvAttentionDeconv(nn.Module):
                  kernel_size: int = 5, residual_attn: bool = True, use_layer_norm: bool = False,
                  max_path_length: int = 100, use_temporal_attention: bool = True):
         super().__init__()
-        if use_layer_norm or not use_temporal_attention:
-            raise NotImplementedError("use_layer_norm / use_temporal_attention=False are not selected by any "
-                                      "exp_spec (SURVEY.md section 8f, row F4)")
+        if use_layer_norm:
+            raise NotImplementedError("use_layer_norm is not selected by any exp_spec (SURVEY.md section 8f, row F4)")
+        if not use_temporal_attention:
+            # the reference builds TemporalSelfAttention layers regardless (ma_temporal.py:277-294) and then calls them
+            # without the time embedding (:382,:399): its forward raises TypeError.  Nothing to be compatible with.
+            raise NotImplementedError("use_temporal_attention=False cannot run in the reference either "
+                                      "(ma_temporal.py:382 calls TemporalSelfAttention.forward without its time argument)")
         self.n_agents = n_agents
         self.history_horizon = history_horizon
         self.use_temporal_attention = use_temporal_attention
@@ -344,12 +428,7 @@ class SharedConvAttentionDeconv(nn.Module):
     # every Linear(Mish(t_emb)) of the live graph, in execution order, evaluated by ONE GEMM per forward
     def _time_layers(self):
         net = self.net
-        blocks: List[ResidualTemporalBlock] = []
-        for r1, r2, _ in net.downs:
-            blocks += [r1, r2]
-        blocks += [net.mid_block1, net.mid_block2]
-        for r1, r2, _ in net.ups:
-            blocks += [r1, r2]
+        blocks = net.rtb_blocks()
         layers = [b.time_mlp[1] for b in blocks]
         n_live_attn = 1 + len(net.ups)          # self_attn[len(ups)+1:] are constructed but never called
         for i in range(n_live_attn):

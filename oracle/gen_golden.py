@@ -100,7 +100,7 @@ def load_reference():
     mod("diffusers.schedulers.scheduling_ddpm", DDPMScheduler=StubDDPMScheduler)
     mod("diffusers.schedulers.scheduling_ddim", DDIMScheduler=StubDDIMScheduler)
     out = {}
-    for name in ("helpers", "temporal", "ma_temporal", "diffusion"):
+    for name in ("helpers", "temporal", "ma_temporal", "ma_temporal_wrappers", "diffusion"):
         spec = importlib.util.spec_from_file_location(f"diffuser.models.{name}", f"{REF}/models/{name}.py")
         mm = importlib.util.module_from_spec(spec)
         sys.modules[f"diffuser.models.{name}"] = mm
@@ -474,7 +474,86 @@ def gen_env_ts(R):
     save("g8_env_ts", **out)
 
 
+def gen_alternates(R):
+    """g9: the non-temporal SelfAttention (helpers.py:77-124), TemporalUnet.forward
+    (temporal.py:348-406), the three wrapper denoisers (ma_temporal_wrappers.py) and the SMAC data encoder
+    (utils/data_encoder.py:11-20) inside GaussianDiffusion -- all from the reference's own files, small width."""
+    H, T, W, D = R["helpers"], R["temporal"], R["ma_temporal_wrappers"], R["diffusion"]
+    out = {}
+    # --- SelfAttention as a module
+    att = H.SelfAttention(64, 4, 16, residual=True)
+    fill_closed_form(att, "selfattn.")
+    x = u("g9.selfattn.x", (2, 5, 64, 6)).requires_grad_(True)
+    y = att(x)
+    gy = u("g9.selfattn.gy", tuple(y.shape))
+    y.backward(gy)
+    out.update({"selfattn.x": x.detach(), "selfattn.y": y, "selfattn.gy": gy, "selfattn.gx": x.grad})
+    for k, p in att.named_parameters():
+        out["selfattn.gp." + k] = p.grad
+    # --- U-Net alone and the wrappers
+    B, Tn = 3, 24
+
+    def run(tag, net, xshape, rshape, n_masks):
+        fill_closed_form(net, "model.")
+        x = u(f"g9.{tag}.x", xshape)
+        t = torch.tensor(T_DRAWS[:B])
+        ret = u(f"g9.{tag}.ret", rshape, 0.0, 1.0)
+        with torch.no_grad():
+            y_c = net(x, t, returns=ret, use_dropout=False)
+            y_u = net(x, t, returns=ret, use_dropout=False, force_dropout=True)
+        with Recorder() as rec:
+            xg = x.clone().requires_grad_(True)
+            y = net(xg, t, returns=ret, use_dropout=True)
+        masks = rec.of("bern")
+        assert len(masks) == n_masks, (tag, len(masks))
+        gy = u(f"g9.{tag}.gy", tuple(y.shape))
+        y.backward(gy)
+        names, rows = grad_digest([(k, p.grad) for k, p in net.named_parameters() if p.grad is not None])
+        out.update({f"{tag}.x": x, f"{tag}.t": t, f"{tag}.returns": ret, f"{tag}.y_cond": y_c, f"{tag}.y_uncond": y_u,
+                    f"{tag}.dropout_masks": torch.stack(masks), f"{tag}.y_drop": y, f"{tag}.gy": gy, f"{tag}.gx": xg.grad,
+                    f"{tag}.gp_names": names, f"{tag}.gp_digest": rows})
+
+    kw = dict(dim=16, dim_mults=(1, 4, 8), returns_condition=True, condition_dropout=0.25)
+    run("unet", quiet(T.TemporalUnet, horizon=Tn, transition_dim=18, **kw), (B, Tn, 18), (B, 1), 1)
+    run("concat", quiet(W.ConcatenatedTemporalUnet, n_agents=3, horizon=Tn, transition_dim=6, **kw), (B, Tn, 3, 6), (B, 1, 3), 1)
+    run("indep", quiet(W.IndependentTemporalUnet, n_agents=2, horizon=Tn, transition_dim=10, **kw), (B, Tn, 2, 10), (B, 1, 2), 2)
+    run("shared_indep", quiet(W.SharedIndependentTemporalUnet, n_agents=3, horizon=Tn, history_horizon=0, transition_dim=10,
+                              **kw), (B, Tn, 3, 10), (B, 1, 3), 1)
+    # --- SMAC data encoder inside GaussianDiffusion: loss and a K = 8 sample
+    spec = importlib.util.spec_from_file_location("ref_data_encoder", REF + "/utils/data_encoder.py")
+    de = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(de)
+    M = R["ma_temporal"]
+    A, Tt, Fd, hh, act, K = 3, 24, 18, 0, 5, 8
+    net = quiet(M.SharedConvAttentionDeconv, horizon=Tt, transition_dim=Fd, dim=16, history_horizon=hh, dim_mults=(1, 4, 8),
+                n_agents=A, returns_condition=True, condition_dropout=0.25)
+    dif = quiet(D.GaussianDiffusion, net, n_agents=A, horizon=Tt, history_horizon=hh, observation_dim=Fd, action_dim=act,
+                n_timesteps=K, returns_condition=True, condition_guidance_w=1.2, hidden_dim=64,
+                data_encoder=de.SMAC3mEncoder())
+    fill_closed_form(dif)
+    batch = O.synthetic_batch(3, Tt, A, Fd, act, hh, False, 0, seed=21)
+    with Recorder() as rec:
+        loss, info = dif.loss(**batch)
+        loss.backward()
+    names, rows = grad_digest([(k, p.grad) for k, p in dif.named_parameters() if p.grad is not None])
+    out.update({"enc.t": rec.of("randint")[0], "enc.noise": rec.of("randn_like")[0], "enc.dropout_mask": rec.of("bern")[0],
+                "enc.loss": loss.detach(), "enc.a0_loss": info["a0_loss"].detach(), "enc.gp_names": names,
+                "enc.gp_digest": rows})
+    sb = O.synthetic_batch(2, Tt, A, Fd, act, hh, False, 0, seed=22)
+    with Recorder(closed_form_randn="g9enc") as rec:
+        xs = dif.conditional_sample(sb["cond"], returns=sb["returns"], verbose=False)
+    assert len(rec.of("randn")) == K
+    out.update({"enc.sample": xs, "enc.cond_x": sb["cond"]["x"], "enc.cond_masks": sb["cond"]["masks"],
+                "enc.returns": sb["returns"]})
+    save("g9_alternates", **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "alternates":
+        torch.manual_seed(1234)
+        torch.set_num_threads(8)
+        gen_alternates(load_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "masks":
         gen_masks()
         return
@@ -498,6 +577,7 @@ def main():
     gen_denoiser_grads_w128(R)
     gen_loss_w128(R)
     gen_env_ts(R)
+    gen_alternates(R)
 
 
 if __name__ == "__main__":
