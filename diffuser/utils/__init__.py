@@ -6,7 +6,11 @@ from madiff_amd.host import (  # noqa: F401
     apply_dict,
     batch_to_device,
     batchify,
+    build_config_from_dict,
+    discover_latest_checkpoint_path,
     import_class,
+    report_parameters,
+    set_device,
     set_seed,
     to_device,
     to_np,

@@ -105,6 +105,59 @@ def batch_to_device(batch, device="cuda:0"):
     return {k: to_device(v, device) for k, v in batch.items()}
 
 
+def set_device(device):
+    """utils/arrays.py:102-106 without the global default-tensor-type switch (deprecated in this torch)."""
+    global DEVICE
+    DEVICE = device
+
+
+def _to_str(num):
+    return f"{num / 1e6:.2f} M" if num >= 1e6 else f"{num / 1e3:.2f} k"
+
+
+def report_parameters(model, topk=10):
+    """Parameter count with the top-k tensors listed (utils/arrays.py:131-149); returns the total."""
+    counts = {k: p.numel() for k, p in model.named_parameters()}
+    total = sum(counts.values())
+    print(f"[ utils/arrays ] Total parameters: {_to_str(total)}")
+    modules = dict(model.named_modules())
+    keys = sorted(counts, key=lambda k: -counts[k])
+    for key in keys[:topk]:
+        print(" " * 8, f"{key:10}: {_to_str(counts[key])} | {modules[key.rpartition('.')[0]]}")
+    rest = keys[topk:]
+    print(" " * 8, f"... and {len(rest)} others accounting for {_to_str(sum(counts[k] for k in rest))} parameters")
+    return total
+
+
+def discover_latest_checkpoint_path(checkpoint_dir):
+    """Newest ``state_<step>.pt`` in a directory, or None (utils/launcher_util.py:17-29)."""
+    import os
+    import re
+    try:
+        names = os.listdir(checkpoint_dir)
+    except FileNotFoundError:
+        return None
+    steps = [int(m.group(1)) for m in (re.fullmatch(r"state_(\d+)\.pt", n) for n in names) if m]
+    return os.path.join(checkpoint_dir, f"state_{max(steps)}.pt") if steps else None
+
+
+def build_config_from_dict(specs, Config=None):
+    """A class whose attributes are the experiment spec (utils/launcher_util.py:32-40).  The reference derives the
+    class from params_proto's ParamsProto; without that package a plain class carries the same attributes."""
+    if Config is None:
+        try:
+            from params_proto.neo_proto import ParamsProto as _Base
+        except ImportError:
+            _Base = object
+
+        class Config(_Base):
+            pass
+
+    for k, v in specs.items():
+        setattr(Config, k, v)
+    return Config
+
+
 def set_seed(seed):
     random.seed(seed)
     np.random.seed(seed)
