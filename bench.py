@@ -99,6 +99,9 @@ KERNEL_DESC = {
 }
 
 
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
 def load_traffic(kernel, launches_per_step):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
     in separate runs of this same command by scripts/pmc_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
@@ -155,7 +158,7 @@ def cpu_baseline(seconds_budget=30.0):
                       f"{BATCH} windows (same shape), after 1 warm-up step: {dt:.1f} s"}
 
 
-def cpu_baseline_sample(episodes=32, steps=5, seconds_budget=40.0):
+def cpu_baseline_sample(episodes=64, steps=5, seconds_budget=12.0):
     """BASELINE.md section 3 "Sample": the oracle's guided K-step loop (2 forwards per step, fp32, torch CPU) on this box's
     host cores, timed over >= `steps` denoising steps on `episodes` episodes of the current sampling shape and
     EXTRAPOLATED to K steps (a full K=200 run takes tens of minutes on the host)."""
@@ -186,7 +189,7 @@ def cpu_baseline_sample(episodes=32, steps=5, seconds_budget=40.0):
     x = one(0, x)                                   # warm-up
     t0 = time.time()
     n = 0
-    while n < steps or (time.time() - t0 < seconds_budget * 0.4 and n < 20):
+    while n < steps or (time.time() - t0 < seconds_budget and n < K_DIFF - 2):
         x = one(1 + n, x)
         n += 1
     dt = time.time() - t0
@@ -413,9 +416,17 @@ def main():
         d = summ[dom]
         traffic = load_traffic(dom, d["launches"] / args.steps)
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        kernels = {k: {"launches_per_step": v["launches"] / args.steps, "avg_us": 1e3 * v["ms"] / v["launches"],
-                       "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
-                       "share_of_step": v["ms"] / (dt * 1e3)} for k, v in summ.items()}
+        kernels = {}
+        for k, v in summ.items():
+            rec = {"launches_per_step": v["launches"] / args.steps, "avg_us": 1e3 * v["ms"] / v["launches"],
+                   "share_of_step": v["ms"] / (dt * 1e3)}
+            if v.get("bytes", 0.0) > 0:          # HBM-bound family: algorithmic bytes / measured time against 8 TB/s
+                gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                rec.update({"bound": "hbm", "algorithmic_mb_per_launch": v["bytes"] / v["launches"] / 1e6, "gbps": gbs,
+                            "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+            else:
+                rec.update({"bound": "mfma", "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12})
+            kernels[k] = rec
         fwd_flops_step = FWD_GF_PER_SAMPLE * 1e9 * BATCH
         out = {
             "metric": "denoiser train samples/sec", "value": train_sps, "unit": "samples/s", "n_gpus": world,

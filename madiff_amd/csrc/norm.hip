@@ -160,6 +160,21 @@ template <> __device__ __forceinline__ void load_vec<float>(const float* p, floa
 #pragma unroll
   for (int i = 0; i < 4; i++) f[i] = v[i];
 }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// a raw 16-byte vector (loaded early, converted when it is used)
+template <typename T> __device__ __forceinline__ void cvt_vec(const u32x4& v, float (&f)[Vec<T>::E]);
+template <> __device__ __forceinline__ void cvt_vec<bf16_t>(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+    f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void cvt_vec<float>(const u32x4& v, float (&f)[4]) {
+  const f32x4 w = __builtin_bit_cast(f32x4, v);     // whole-vector cast (an element-wise cast of v[i] lost lanes 2, 3)
+#pragma unroll
+  for (int i = 0; i < 4; i++) f[i] = w[i];
+}
 template <typename T> __device__ __forceinline__ void store_vec(T* p, const float (&f)[Vec<T>::E]);
 template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const float (&f)[8]) {
   bf16x8 v;
@@ -444,9 +459,38 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_rb_kernel(
   float gm[E], bt[E], a_dg[E], a_db[E], a_dbias[E];
 #pragma unroll
   for (int e = 0; e < E; e++) { gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; a_dg[e] = a_db[e] = a_dbias[e] = 0.f; }
-  for (int n = blockIdx.y * 4 + wave; n < N; n += gridDim.y * 4) {
+  // Software pipeline over the wave's sequences: the raw 16-byte vectors (and the statistics) of the NEXT sequence are
+  // requested before the current one is worked on, so the loads fly under the ~50 VALU instructions per element.
+  const int nstep = gridDim.y * 4;
+  int n = blockIdx.y * 4 + wave;
+  u32x4 ry[VPL], rd[VPL];
+  float mean = 0.f, rstd = 0.f;
+  // (loads are unconditional - a row past the sequence re-reads its last row, the step past the last sequence re-reads
+  // the current one - so the code is straight-line and the waits can be counted instead of draining everything)
+  if (n < N) {
+    const size_t rb0 = (size_t)n * Tn;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      const int r = min(r0 + i * RPI, Tn - 1);
+      ry[i] = *(const u32x4*)(y + (rb0 + r) * ldy + c0);
+      rd[i] = *(const u32x4*)(dout + (rb0 + r) * ldd + c0);
+    }
+    mean = mean_in[(size_t)n * G + g];
+    rstd = rstd_in[(size_t)n * G + g];
+  }
+  for (; n < N; n += nstep) {
     const size_t rbase = (size_t)n * Tn;
-    const float mean = mean_in[(size_t)n * G + g], rstd = rstd_in[(size_t)n * G + g];
+    const int nn = n + nstep < N ? n + nstep : n;
+    u32x4 ny[VPL], nd[VPL];
+    const size_t rb1 = (size_t)nn * Tn;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      const int r = min(r0 + i * RPI, Tn - 1);
+      ny[i] = *(const u32x4*)(y + (rb1 + r) * ldy + c0);
+      nd[i] = *(const u32x4*)(dout + (rb1 + r) * ldd + c0);
+    }
+    const float nmean = mean_in[(size_t)nn * G + g];
+    const float nrstd = rstd_in[(size_t)nn * G + g];
     float xh[VPL][E], dxh[VPL][E], rbs[E];
 #pragma unroll
     for (int e = 0; e < E; e++) rbs[e] = 0.f;
@@ -456,8 +500,8 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_rb_kernel(
       const int r = r0 + i * RPI;
       if (r < Tn) {
         float yv[E], go[E];
-        load_vec<T>(y + (rbase + r) * ldy + c0, yv);
-        load_vec<T>(dout + (rbase + r) * ldd + c0, go);
+        cvt_vec<T>(ry[i], yv);
+        cvt_vec<T>(rd[i], go);
 #pragma unroll
         for (int e = 0; e < E; e++) {
           const float x = (yv[e] - mean) * rstd;
@@ -499,6 +543,10 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_rb_kernel(
         for (int e = 0; e < E; e++) drowbias[(size_t)n * ldrb + c0 + e] = rbs[e];
       }
     }
+#pragma unroll
+    for (int i = 0; i < VPL; i++) { ry[i] = ny[i]; rd[i] = nd[i]; }
+    mean = nmean;
+    rstd = nrstd;
   }
 #pragma unroll
   for (int e = 0; e < E; e++) {
@@ -589,7 +637,7 @@ static int gn_bwd_rb(int dtype, const void* y, int ldy, const void* dout, int ld
     return 1;
   const int ranges = (C / E) >> cl;
   static int wgs = -1;
-  if (wgs < 0) { const char* e = getenv("MADIFF_GN_BWD_WGS"); wgs = e ? atoi(e) : 1024; }
+  if (wgs < 0) { const char* e = getenv("MADIFF_GN_BWD_WGS"); wgs = e ? atoi(e) : 512; }
   int nb = wgs / ranges;                        // workgroups in flight (each ends with one atomic per channel)
   if (nb > (N + 3) / 4) nb = (N + 3) / 4;
   if (nb < 1) nb = 1;

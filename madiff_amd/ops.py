@@ -291,7 +291,7 @@ def clear_pack_cache() -> None:
 # optional per-launch timing with HIP events on the launch stream (bench.py's roofline figures)
 # ------------------------------------------------------------------------------------------------
 class KernelTimer:
-    """Collects (kernel name, algorithmic FLOPs, start event, stop event) per launch while installed."""
+    """Collects (kernel name, algorithmic FLOPs, algorithmic bytes, start event, stop event) per launch while installed."""
 
     def __init__(self):
         self.records = []
@@ -299,11 +299,12 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, e0, e1 in self.records:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for name, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += flops
+            d["bytes"] += nbytes
         return out
 
 
@@ -331,34 +332,36 @@ class GraphKernelTimer:
         self.totals = {}
         self.replays = 0
 
-    def bracket(self, name, flops, launch):
+    def bracket(self, name, flops, launch, nbytes=0.0, stream=None):
         import ctypes
         h0, h1 = ctypes.c_void_p(), ctypes.c_void_p()
+        st = _stream() if stream is None else stream.cuda_stream
         lib.call("madiff_event_create_timed", ctypes.byref(h0))
         lib.call("madiff_event_create_timed", ctypes.byref(h1))
-        lib.call("madiff_event_record_external", h0.value, _stream())
+        lib.call("madiff_event_record_external", h0.value, st)
         used = launch()
-        lib.call("madiff_event_record_external", h1.value, _stream())
+        lib.call("madiff_event_record_external", h1.value, st)
         if used != "":
-            self.pairs.append((used if isinstance(used, str) else name, flops, h0.value, h1.value))
+            self.pairs.append((used if isinstance(used, str) else name, flops, nbytes, h0.value, h1.value))
 
     def collect(self):
         import ctypes
         torch.cuda.synchronize()
         ms = ctypes.c_float()
-        for name, flops, h0, h1 in self.pairs:
+        for name, flops, nbytes, h0, h1 in self.pairs:
             lib.call("madiff_event_elapsed_ms", h0, h1, ctypes.byref(ms))
-            d = self.totals.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d = self.totals.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += ms.value
             d["flops"] += flops
+            d["bytes"] += nbytes
         self.replays += 1
 
     def summary(self):
         return self.totals
 
     def close(self):
-        for _, _, h0, h1 in self.pairs:
+        for _, _, _, h0, h1 in self.pairs:
             lib.call("madiff_event_destroy", h0)
             lib.call("madiff_event_destroy", h1)
         self.pairs = []
@@ -367,20 +370,21 @@ class GraphKernelTimer:
 GRAPH_TIMER: Optional[GraphKernelTimer] = None
 
 
-def _timed(name: str, flops: float, launch):
-    """launch() may return the name of the kernel it actually dispatched to (overrides `name`)."""
+def _timed(name: str, flops: float, launch, nbytes: float = 0.0, stream=None):
+    """launch() may return the name of the kernel it actually dispatched to (overrides `name`).  `nbytes` = algorithmic
+    HBM bytes of the launch (the HBM-bound families); `stream` = the stream the launch goes to when it is not the current one."""
     if TIMER is None:
         if GRAPH_TIMER is not None and torch.cuda.is_current_stream_capturing():
-            GRAPH_TIMER.bracket(name, flops, launch)
+            GRAPH_TIMER.bracket(name, flops, launch, nbytes, stream)
             return
         launch()
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    e0.record(stream)
     used = launch()
-    e1.record()
+    e1.record(stream)
     if used != "":
-        TIMER.records.append((used if isinstance(used, str) else name, flops, e0, e1))
+        TIMER.records.append((used if isinstance(used, str) else name, flops, nbytes, e0, e1))
 
 
 def graph_capture(graph):
@@ -956,9 +960,12 @@ def _gn_forward(y, gamma, beta, rowbias, res, n_seq, t, C, G):
         assert rowbias.dtype == torch.float32 and rowbias.stride(1) == 1
     if res is not None:
         _chk_cl(res)
-    lib.call("madiff_gn_mish_fwd", _dt(), y.data_ptr(), y.stride(0), out.data_ptr(), out.stride(0), gamma.data_ptr(),
-             beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), n_seq, t, C, cpad, G, 1e-5, mode, _p(rowbias),
-             0 if rowbias is None else rowbias.stride(0), _p(res), 0 if res is None else res.stride(0), _stream())
+    es = y.element_size()                      # algorithmic bytes: read y (+ residual), write out
+    _timed("gn_mish_fwd_rb_kernel", 0.0, lambda: lib.call(
+        "madiff_gn_mish_fwd", _dt(), y.data_ptr(), y.stride(0), out.data_ptr(), out.stride(0), gamma.data_ptr(),
+        beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), n_seq, t, C, cpad, G, 1e-5, mode, _p(rowbias),
+        0 if rowbias is None else rowbias.stride(0), _p(res), 0 if res is None else res.stride(0), _stream()),
+        nbytes=float(n_seq * t * C * es * (3 if mode == 2 else 2)))
     return out, stats, (n_seq, t, C, cpad, G, mode)
 
 
@@ -974,10 +981,11 @@ def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None):
         tmp = torch.zeros(len(plist), C, dtype=torch.float32, device=y.device)
     bufs = [v if v is not None else tmp[i] for i, v in enumerate(views)]
     drb = torch.empty(n_seq, C, dtype=torch.float32, device=y.device) if mode == 1 else None
-    lib.call("madiff_gn_mish_bwd", _dt(), y.data_ptr(), y.stride(0), dout.data_ptr(), dout.stride(0), dy.data_ptr(),
-             dy.stride(0), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-             bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr() if conv_bias is not None else None, _p(drb), C,
-             n_seq, t, C, cpad, G, _stream())
+    _timed("gn_mish_bwd_rb_kernel", 0.0, lambda: lib.call(           # algorithmic bytes: read y and dout, write dy
+        "madiff_gn_mish_bwd", _dt(), y.data_ptr(), y.stride(0), dout.data_ptr(), dout.stride(0), dy.data_ptr(),
+        dy.stride(0), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+        bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr() if conv_bias is not None else None, _p(drb), C,
+        n_seq, t, C, cpad, G, _stream()), nbytes=float(3 * n_seq * t * C * y.element_size()))
     outs = []
     for p_, v, b in zip(plist, views, bufs):
         if v is not None:
@@ -1112,8 +1120,10 @@ class AttnCore(torch.autograd.Function):
         out = torch.empty_like(x)
         if out.shape[1] > C:
             out[:, C:].zero_()
-        lib.call("madiff_attn_fwd", _dt(), qkv.data_ptr(), qkv.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
-                 out.stride(0), _p(gamma), B, A, T, H, Cq, C, int(residual), _stream())
+        _timed("attn_fwd_v2_kernel", 0.0, lambda: lib.call(             # bytes: read qkv and x, write out
+            "madiff_attn_fwd", _dt(), qkv.data_ptr(), qkv.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
+            out.stride(0), _p(gamma), B, A, T, H, Cq, C, int(residual), _stream()),
+            nbytes=float(B * A * T * (2 * Cq + 3 * C) * x.element_size()))
         ctx.save_for_backward(qkv, gamma)
         ctx.geom = (B, A, T, H, Cq, C, residual)
         return out
@@ -1128,8 +1138,10 @@ class AttnCore(torch.autograd.Function):
             dqkv[:, 2 * Cq + C:].zero_()
         view = _sink_view(gamma) if residual else None
         dgamma = view if view is not None else (torch.zeros(1, dtype=torch.float32, device=qkv.device) if residual else None)
-        lib.call("madiff_attn_bwd", _dt(), qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0),
-                 dqkv.data_ptr(), dqkv.stride(0), _p(gamma), _p(dgamma), B, A, T, H, Cq, C, int(residual), _stream())
+        _timed("attn_bwd_v2_kernel", 0.0, lambda: lib.call(             # bytes: read qkv and dout, write dqkv
+            "madiff_attn_bwd", _dt(), qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0),
+            dqkv.data_ptr(), dqkv.stride(0), _p(gamma), _p(dgamma), B, A, T, H, Cq, C, int(residual), _stream()),
+            nbytes=float(B * A * T * (2 * (2 * Cq + C) + C) * qkv.element_size()))
         if view is not None:
             SINK.done(gamma)
             dgamma = None

@@ -209,11 +209,14 @@ class FlatAdamEMA:
         b1, b2 = self.betas
         step = self.step_count + 1
         e = None if self.flat_ema is None else self.flat_ema.data_ptr() + 4 * lo
-        lib.call("madiff_adam_ema", self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
-                 self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, e, hi - lo, self.lr, b1, b2, self.eps,
-                 1 - b1 ** step, math.sqrt(1 - b2 ** step), self.grad_scale / self.world, do_ema, self.ema_decay,
-                 None if device_state is None else device_state.data_ptr(), self.flat_p16.data_ptr() + 2 * lo, 3,
-                 stream.cuda_stream)
+        # algorithmic bytes per element: read p, g, m, v (16), write p, m, v, zeroed g (16), bf16 copy (2); the EMA pass of
+        # every 10th step (+8) is not counted
+        ops._timed("adam_ema_kernel", 0.0, lambda: lib.call(
+            "madiff_adam_ema", self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
+            self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, e, hi - lo, self.lr, b1, b2, self.eps,
+            1 - b1 ** step, math.sqrt(1 - b2 ** step), self.grad_scale / self.world, do_ema, self.ema_decay,
+            None if device_state is None else device_state.data_ptr(), self.flat_p16.data_ptr() + 2 * lo, 3,
+            stream.cuda_stream), nbytes=34.0 * (hi - lo), stream=stream)
 
     def _order_behind_producers(self, tgt):
         """Make `tgt` wait for every stream a member of the bucket may have been produced on: the stream that is current

@@ -1,5 +1,5 @@
 """Per-step breakdown from a rocprofv3 kernel trace: takes the LAST `nsteps` optimizer steps (delimited by the
-mse_fwd_kernel dispatches, one per step), and prints, per (kernel, grid) bucket, launches per step, average duration and share, plus
+loss_finish_kernel dispatches, one per step), and prints, per (kernel, grid) bucket, launches per step, average duration and share, plus
 GPU busy time vs wall time per step (the difference is launch gaps / host-bound time).
 usage: python scripts/trace_steps.py <dir with *_kernel_trace.csv> [nsteps=5] [topN=40] [skip_last_steps=0]"""
 import csv, glob, os, sys, collections, re
@@ -11,8 +11,10 @@ skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # ignore the last `skip
 f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# one mse_fwd_kernel per optimizer step (the Adam/EMA pass is issued in per-bucket slices all over backward)
-adam = [i for i, r in enumerate(rows) if "mse_fwd_kernel" in r["Kernel_Name"]]
+# one loss_finish_kernel (fused loss; mse_fwd_kernel before it existed) per optimizer step (the Adam/EMA pass is issued in
+# per-bucket slices all over backward)
+mark = "loss_finish_kernel" if any("loss_finish_kernel" in r["Kernel_Name"] for r in rows) else "mse_fwd_kernel"
+adam = [i for i, r in enumerate(rows) if mark in r["Kernel_Name"]]
 assert len(adam) > nsteps + skip, "not enough optimizer steps in the trace"
 lo, hi = adam[-nsteps - 1 - skip] + 1, adam[-1 - skip] + 1
 sel = rows[lo:hi]
