@@ -92,6 +92,14 @@ int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, int taps, int
                          int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad, void* dX, int ldx,
                          int tile, int ksplit, madiff_stream_t stream);
 
+/* madiff_gemm_dgrad_wt with an addend: dX = data gradient + addend (bf16 [M, ld_add], pad columns zero, may be NULL).
+   Merges the two gradient contributions of a tensor with two consumers - ResidualTemporalBlock's input feeds blocks[0]
+   and residual_conv (reference diffuser/models/temporal.py:197-200; torch autograd adds them in a separate pass).
+   Returns 1 when the selected kernel has no vector epilogue for this layer: the caller then adds itself. */
+int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred, int taps, int T_out, int T_in, int stride, int pad,
+                             int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad, void* dX, int ldx,
+                             int tile, int ksplit, const void* addend, int ld_add, madiff_stream_t stream);
+
 /* Weight gradient of the above: dW[o, tap*Cin + c] (+)= sum_m dY[m, o] * X[src(m, tap), c]  (fp32 output).
  * Replaces the wgrad half of autograd for the same modules.  accumulate != 0 adds into dW (a live gradient buffer
  * kept in this GEMM layout by the flat optimizer), 0 overwrites.  tile: variant of the gfx950 LDS-DMA kernel, < 0 =
@@ -197,6 +205,20 @@ int madiff_loss_bwd(const float* eps, const float* noise, const float* w, const 
                     long pred_rs, long pred_as, const float* x, const float* legal, int B, int T, int A, int F, int act,
                     int nout, int discrete, const float* mse_sums, const double* out, const void* go, int go_f64,
                     float* d_eps, float* d_pred, madiff_stream_t stream);
+
+/* madiff_loss_fwd / _bwd for `segments` micro-batches of one optimizer step folded along the batch axis (B % segments == 0):
+   the gradient of (1/S) * sum of the S separate loss() calls of the reference's accumulation loop
+   (diffuser/utils/training.py:147-152), in one pass -- the inverse-dynamics part is normalised by each micro-batch's own
+   mask mean (diffuser/models/diffusion.py:407,418).  workspace: segments * madiff_loss_ws_doubles() doubles; out / out_f:
+   6 * (1 + segments) values = the means over the micro-batches, then the six of every micro-batch. */
+int madiff_loss_fwd_seg(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64,
+                        const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B, int T, int A,
+                        int F, int act, int nout, int discrete, int segments, float* mse_sums, double* workspace, double* out,
+                        float* out_f, madiff_stream_t stream);
+int madiff_loss_bwd_seg(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64,
+                        const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B, int T, int A,
+                        int F, int act, int nout, int discrete, int segments, const float* mse_sums, const double* out,
+                        const void* go, int go_f64, float* d_eps, float* d_pred, madiff_stream_t stream);
 /* Inputs of the inverse-dynamics MLP (diffusion.py:381-384): rows [o_t | o_{t+1}] for t < T-1 in the activation layout
  * (storage type, ld columns, pad zeroed).  joint = 0: one row per (b, t, a); joint = 1: one row per (b, t), agents
  * concatenated (joint_inv). */

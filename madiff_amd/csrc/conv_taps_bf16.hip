@@ -491,6 +491,11 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = n + e < p.Nout ? mish_f(v[e]) : 0.f;
       }
+      if (p.addend) {
+        const bf16x8 ad = *(const bf16x8*)((const bf16_t*)p.addend + (size_t)m * p.lda + n);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] += (float)ad[e];
+      }
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; e++) o[e] = (bf16_t)v[e];
@@ -520,6 +525,7 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_bf1
   const bool vec_ok = p.Npad % 8 == 0 && ((size_t)p.C % 16) == 0 && ((size_t)p.ldc * 2) % 16 == 0 &&
                       (!p.bias || (size_t)p.bias % 16 == 0) && (!p.rowbias || ((size_t)p.rowbias % 16 == 0 && p.ldrb % 4 == 0));
   if (!vec_ok) return 1;
+  if (p.addend && (((size_t)p.addend % 16) || p.lda % 8 || p.lda < p.Npad)) return 1;
   const int spt = BM / T, rows_used = spt * T;
   const int n_seq = p.M / T;
   const int shift0 = p.rm.tr ? p.rm.pad : -p.rm.pad, shift_step = p.rm.tr ? -1 : 1;

@@ -417,7 +417,7 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Npad; p.bias = bias; p.rowbias = rowbias; p.ldrb = ldrb;
   p.C = C; p.ldc = ldc; p.act = act; p.permT = permT; p.permA = permA;
-  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0;
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.addend = nullptr; p.lda = 0;
   dim3 grid((M + 127) / 128, (Npad + 127) / 128), block(256);
   if (tile >= kFirstTapsTile) {
     if (dtype != MADIFF_BF16 || !use_dma_kernel()) return 1;
@@ -456,10 +456,15 @@ extern "C" int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, i
   p.rm = RowMap{T, T, 1, 2, 0};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Nout; p.bias = bias; p.rowbias = nullptr; p.ldrb = 0;
   p.C = Y; p.ldc = ldy; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1;
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0;
   return madiff_launch_conv_taps_gn_bf16(&p, variant, out, ldo, gamma, beta, mean, rstd, G, eps, mode, rowbias, ldrb, res,
                                          ldr, Y != nullptr, stream);
 }
+
+extern "C" int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred, int taps, int T_out, int T_in, int stride,
+                                        int pad, int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad,
+                                        void* dX, int ldx, int tile, int ksplit, const void* addend, int ld_add,
+                                        hipStream_t stream);
 
 // Data gradient of a layer straight from its FORWARD bf16 weight matrix W [Kred = Opad rows, ldw = taps*wtap]:
 //   dX[m, n] = sum_{tap, o} dY[src(m, tap), o] * W[o, tap*wtap + wcol0 + n],   n < Ncols
@@ -471,7 +476,19 @@ extern "C" int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, i
 extern "C" int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, int taps, int T_out, int T_in, int stride,
                                     int pad, int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad,
                                     void* dX, int ldx, int tile, int ksplit, hipStream_t stream) {
+  return madiff_gemm_dgrad_wt_add(dY, ldy, M, Kred, taps, T_out, T_in, stride, pad, tr, W, ldw, wtap, wcol0, Ncols, Npad, dX,
+                                  ldx, tile, ksplit, nullptr, 0, stream);
+}
+
+// The same with an addend: dX = (the data gradient) + addend[M, ld_add] (bf16, pad columns zero).  This is how the two
+// gradient contributions of a tensor with two consumers (temporal.py:197-200: x feeds blocks[0] and residual_conv) merge
+// without a separate add pass.  Returns 1 when the chosen kernel has no vector epilogue for this layer (caller adds).
+extern "C" int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred, int taps, int T_out, int T_in, int stride,
+                                        int pad, int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad,
+                                        void* dX, int ldx, int tile, int ksplit, const void* addend, int ld_add,
+                                        hipStream_t stream) {
   if (M <= 0 || Ncols <= 0) return 0;
+  if (addend && (ksplit > 1 || ld_add < Npad || ld_add % 8 || ((size_t)addend % 16))) return 1;
   if (!use_dma_kernel() || Kred % 64 || wcol0 % 8 || wtap % 8 || ldw % 8) return 1;
   if (check_rowmap(T_out, T_in, stride, pad, tr) || taps <= 0 || ldy < Kred || ldy % 8 || Npad < Ncols || ldx < Npad ||
       wcol0 < 0 || wcol0 + Ncols > wtap || ldw < taps * wtap || M % T_out || tile >= kNumTiles ||
@@ -484,7 +501,7 @@ extern "C" int madiff_gemm_dgrad_wt(const void* dY, int ldy, int M, int Kred, in
   p.W = (const unsigned char*)W + (size_t)wcol0 * 2; p.ldw = ldw; p.Nout = Ncols; p.Npad = Npad;
   p.bias = nullptr; p.rowbias = nullptr; p.ldrb = 0;
   p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0;
+  p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0; p.addend = addend; p.lda = ld_add;
   const int nsteps = (Kred / 64) * taps;
   p.ksplit = ksplit > 1 ? (ksplit < nsteps ? ksplit : nsteps) : 0;
   if (p.ksplit > 1) {

@@ -249,6 +249,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = n + e < p.Nout ? mish_f(v[e]) : 0.f;
         }
+        if (p.addend) {                       // (launcher: bf16 output, no row permutation; pad columns of the addend are 0)
+          const bf16x8 ad = *(const bf16x8*)((const bf16_t*)p.addend + (size_t)m * p.lda + n);
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] += (float)ad[e];
+        }
         OutT* dst = C + orow * p.ldc + n;
         if constexpr (sizeof(OutT) == 2) {
           bf16x8 o;
@@ -350,6 +355,7 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_fwd_bf16
     p.vec_epi = p.ksplit <= 1 && p.Npad % 8 == 0 && ((size_t)p.C % 16) == 0 && ((size_t)p.ldc * es) % 16 == 0 &&
                 (!p.bias || (size_t)p.bias % 16 == 0) &&
                 (!p.rowbias || ((size_t)p.rowbias % 16 == 0 && p.ldrb % 4 == 0));
+    if (p.addend && (!p.vec_epi || out_f32 || p.permA > 0)) return 1;      // the addend exists in the vector epilogue only
   }
   if (p.wt && out_f32) {     // split-K data gradient: one variant, fp32 atomics
     if (tile != 8) return -1;

@@ -26,6 +26,7 @@ struct GemmFwdParams {
   int wt, wtap, wcols;
   int vec_epi;                       // 1: pointers/strides allow the 16-byte vector epilogue (set by the launcher)
   int ksplit;                        // > 1: gridDim.z slices of the K-steps combine with fp32 atomics (fp32 C, pre-zeroed)
+  const void* addend; int lda;       // bf16 [M, lda] added to the result after the activation (vector epilogues only), or null
 };
 
 struct GemmWgradParams {

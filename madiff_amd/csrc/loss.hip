@@ -26,6 +26,8 @@ struct LossArgs {
   const float* eps; const float* noise; const float* w; const void* masks; int masks_f64;
   const float* pred; long pred_rs, pred_as; const float* x; const float* legal;
   int B, T, A, F, act, nout, discrete;
+  int S;   // micro-batches folded along B (B % S == 0): the inverse-dynamics loss is normalised per micro-batch, as
+           // gradient accumulation over S calls would (training.py:147-152); 1 = one batch
 };
 
 // One (r, a) row of the inverse-dynamics loss.  Returns the row loss (sum of squared errors | cross-entropy) and whether
@@ -96,12 +98,14 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(LossArgs p, float* _
       mse_sums[b * 3 + threadIdx.x] = (float)(red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
     return;
   }
-  const int blk = blockIdx.x - p.B;
-  const long rows = (long)p.B * (p.T - 1) * p.A;
+  const int blk = blockIdx.x - p.B;                        // INV_BLOCKS workgroups per micro-batch
+  const int seg = blk / INV_BLOCKS, sub = blk - seg * INV_BLOCKS;
+  const long rows = (long)(p.B / p.S) * (p.T - 1) * p.A;   // rows of one micro-batch
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (long e = (long)blk * 256 + threadIdx.x; e < rows; e += (long)INV_BLOCKS * 256) {
-    const long r = e / p.A;
-    const int a = (int)(e - r * p.A);
+  for (long e = (long)sub * 256 + threadIdx.x; e < rows; e += (long)INV_BLOCKS * 256) {
+    const long eg = (long)seg * rows + e;
+    const long r = eg / p.A;
+    const int a = (int)(eg - r * p.A);
     const int b = (int)(r / (p.T - 1)), t = (int)(r - (long)b * (p.T - 1));
     const float m = mask_at(p.masks, p.masks_f64, ((long)b * p.T + t + 1) * p.A + a);     // loss_masks[:, 1:]
     int hit;
@@ -114,32 +118,47 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(LossArgs p, float* _
   if (threadIdx.x < 3) part[blk * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 
-// out (double) / out_f (float): {loss, a0_loss, inv_loss, inv_acc, inverse-dynamics mask sum, diffuse_loss}
+// out (double) / out_f (float): {loss, a0_loss, inv_loss, inv_acc, inverse-dynamics mask sum, diffuse_loss}; with S > 1
+// micro-batches these six are the means over the micro-batches (entry 4: the sum) and six more per micro-batch follow at
+// [6 + 6 s ...] (what each separate loss() call would have returned).
 __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ mse_sums, const double* __restrict__ part,
-                                                          int B, int T, int A, int F, int act, int discrete,
+                                                          int B, int T, int A, int F, int act, int discrete, int S,
                                                           double* __restrict__ out, float* __restrict__ out_f) {
   __shared__ double red[5][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double ratio = 0.0, unmasked = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int b = threadIdx.x; b < B; b += 256) {
-    ratio += (double)mse_sums[b * 3] / (double)mse_sums[b * 3 + 1];
-    unmasked += (double)mse_sums[b * 3 + 2];
+  const int Bs = B / S;
+  double tot[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int sg = 0; sg < S; sg++) {
+    double ratio = 0.0, unmasked = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int b = sg * Bs + threadIdx.x; b < (sg + 1) * Bs; b += 256) {
+      ratio += (double)mse_sums[b * 3] / (double)mse_sums[b * 3 + 1];
+      unmasked += (double)mse_sums[b * 3 + 2];
+    }
+    for (int i = threadIdx.x; i < INV_BLOCKS; i += 256) {
+      const double* q = part + ((long)sg * INV_BLOCKS + i) * 3;
+      s0 += q[0]; s1 += q[1]; s2 += q[2];
+    }
+    ratio = wave_sum_d(ratio); unmasked = wave_sum_d(unmasked); s0 = wave_sum_d(s0); s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    __syncthreads();                           // (the previous micro-batch's sums have been read)
+    if (lane == 0) { red[0][wave] = ratio; red[1][wave] = unmasked; red[2][wave] = s0; red[3][wave] = s1; red[4][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v[5];
+      for (int k = 0; k < 5; k++) v[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+      const double diffuse = v[0] / ((double)Bs * F);
+      const double a0 = v[1] / ((double)Bs * T * A * F);
+      // continuous: mean over (rows, act) of (se * m) / mean over rows of m = S0 / (act * S1); discrete: S0 / S1
+      const double inv = discrete ? v[2] / v[3] : v[2] / ((double)act * v[3]);
+      const double acc = discrete ? v[4] / v[3] : 0.0;
+      const double res[6] = {0.5 * (diffuse + inv), a0, inv, acc, v[3], diffuse};
+      for (int k = 0; k < 6; k++) {
+        tot[k] += k == 4 ? res[k] : res[k] / S;
+        if (S > 1) { out[6 + 6 * sg + k] = res[k]; out_f[6 + 6 * sg + k] = (float)res[k]; }
+      }
+    }
   }
-  for (int i = threadIdx.x; i < INV_BLOCKS; i += 256) { s0 += part[i * 3]; s1 += part[i * 3 + 1]; s2 += part[i * 3 + 2]; }
-  ratio = wave_sum_d(ratio); unmasked = wave_sum_d(unmasked); s0 = wave_sum_d(s0); s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-  if (lane == 0) { red[0][wave] = ratio; red[1][wave] = unmasked; red[2][wave] = s0; red[3][wave] = s1; red[4][wave] = s2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double v[5];
-    for (int k = 0; k < 5; k++) v[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
-    const double diffuse = v[0] / ((double)B * F);
-    const double a0 = v[1] / ((double)B * T * A * F);
-    // continuous: mean over (rows, act) of (se * m) / mean over rows of m = S0 / (act * S1); discrete: S0 / S1
-    const double inv = discrete ? v[2] / v[3] : v[2] / ((double)act * v[3]);
-    const double acc = discrete ? v[4] / v[3] : 0.0;
-    const double res[6] = {0.5 * (diffuse + inv), a0, inv, acc, v[3], diffuse};
-    for (int k = 0; k < 6; k++) { out[k] = res[k]; out_f[k] = (float)res[k]; }
-  }
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 6; k++) { out[k] = tot[k]; out_f[k] = (float)tot[k]; }
 }
 
 // d loss / d eps and d loss / d pred, times the upstream gradient *go.  grid-stride over both ranges in one launch.
@@ -157,13 +176,14 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs p, const float* 
     d_eps[e] = ge * (p.eps[e] - p.noise[e]) * p.w[i] * m / mse_sums[b * 3 + 1];
   }
   const long rows = (long)p.B * (p.T - 1) * p.A;
-  const float s1 = (float)out[4];
-  const float gi = p.discrete ? g / s1 : g / ((float)p.act * s1);
+  const int Bs = p.B / p.S;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < rows; e += (long)gridDim.x * 256) {
     const long r = e / p.A;
     const int a = (int)(e - r * p.A);
     const int b = (int)(r / (p.T - 1)), t = (int)(r - (long)b * (p.T - 1));
     const float m = mask_at(p.masks, p.masks_f64, ((long)b * p.T + t + 1) * p.A + a);
+    const float s1 = p.S > 1 ? (float)out[6 + 6 * (b / Bs) + 4] : (float)out[4];      // the row's micro-batch normalises it
+    const float gi = (p.discrete ? g / s1 : g / ((float)p.act * s1)) / (float)p.S;
     int hit;
     inv_row<true>(p, r, a, &hit, d_pred, gi * m);
     // pad columns behind this agent's block (shared MLP: up to the row's leading dimension; joint MLP: behind the last agent)
@@ -210,15 +230,16 @@ inline int nblk(long total) {
 #define MADIFF_LOSS_WS_DOUBLES (INV_BLOCKS * 3)
 
 static int loss_fwd_impl(const LossArgs& p, float* mse_sums, double* ws, double* out, float* out_f, hipStream_t stream) {
-  hipLaunchKernelGGL(loss_partials_kernel, dim3(p.B + INV_BLOCKS), dim3(256), 0, stream, p, mse_sums, ws);
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, stream, mse_sums, ws, p.B, p.T, p.A, p.F, p.act, p.discrete, out,
-                     out_f);
+  hipLaunchKernelGGL(loss_partials_kernel, dim3(p.B + INV_BLOCKS * p.S), dim3(256), 0, stream, p, mse_sums, ws);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, stream, mse_sums, ws, p.B, p.T, p.A, p.F, p.act, p.discrete, p.S,
+                     out, out_f);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }
 
 static int loss_check(const LossArgs& p) {
   if (p.B <= 0 || p.T < 2 || p.A <= 0 || p.F <= 0 || p.act <= 0 || p.nout <= 0 || p.nout > 256) return -1;
+  if (p.S < 1 || p.S > 64 || p.B % p.S) return -1;
   if (!p.eps || !p.noise || !p.w || !p.masks || !p.pred || !p.x) return -1;
   if (p.pred_as < p.nout && p.A > 1) return -1;
   if (p.pred_rs < (long)(p.A - 1) * p.pred_as + p.nout) return -1;
@@ -233,7 +254,7 @@ extern "C" int madiff_loss_fwd(const float* eps, const float* noise, const float
                                const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B, int T,
                                int A, int F, int act, int nout, int discrete, float* mse_sums, double* workspace, double* out,
                                float* out_f, hipStream_t stream) {
-  LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete};
+  LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete, 1};
   if (loss_check(p) || !mse_sums || !workspace || !out || !out_f) return -1;
   return loss_fwd_impl(p, mse_sums, workspace, out, out_f, stream);
 }
@@ -269,7 +290,7 @@ extern "C" int madiff_loss_fwd_static(const float* eps, const float* noise, cons
                                       const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B,
                                       int T, int A, int F, int act, int nout, int discrete, double* out, float* out_f,
                                       hipStream_t stream) {
-  LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete};
+  LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete, 1};
   if (loss_check(p) || !out || !out_f) return -1;
   if (B > MADIFF_LOSS_STATIC_MAX_B) return -2;            // beyond the static scratch: use madiff_loss_fwd with a workspace
   int rc = madiff_loss_static_init();                     // (first call on this device; a no-op afterwards)
@@ -287,7 +308,7 @@ extern "C" int madiff_loss_bwd(const float* eps, const float* noise, const float
                                const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B, int T,
                                int A, int F, int act, int nout, int discrete, const float* mse_sums, const double* out,
                                const void* go, int go_f64, float* d_eps, float* d_pred, hipStream_t stream) {
-  LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete};
+  LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete, 1};
   if (loss_check(p) || !mse_sums || !out || !go || !d_eps || !d_pred) return -1;
   const long n = (long)B * T * A * F;
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, p, mse_sums, out, go, go_f64, d_eps, d_pred);
@@ -304,6 +325,33 @@ extern "C" int madiff_inv_pairs(int dtype, const float* x, void* out, int ld, in
     hipLaunchKernelGGL((inv_pairs_kernel<bf16_t>), dim3(nblk(total)), dim3(256), 0, stream, x, (bf16_t*)out, ld, B, T, A, act, F, joint);
   else
     hipLaunchKernelGGL((inv_pairs_kernel<float>), dim3(nblk(total)), dim3(256), 0, stream, x, (float*)out, ld, B, T, A, act, F, joint);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- S micro-batches of one optimizer step folded along the batch axis (the reference's gradient_accumulate_every,
+// training.py:147-152: S separate loss() calls, each scaled by 1/S before backward).  One pass over the S*Bs samples gives
+// the same gradient: the denoiser part is normalised per sample, the inverse-dynamics part per micro-batch (its mask mean,
+// diffusion.py:407,418), which is what these entry points do.  workspace: segments * madiff_loss_ws_doubles() doubles;
+// out / out_f: 6 * (1 + segments) values (layout at loss_finish_kernel); segments = 1 is madiff_loss_fwd / _bwd.
+extern "C" int madiff_loss_fwd_seg(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64,
+                                   const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B,
+                                   int T, int A, int F, int act, int nout, int discrete, int segments, float* mse_sums,
+                                   double* workspace, double* out, float* out_f, hipStream_t stream) {
+  LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete, segments};
+  if (loss_check(p) || !mse_sums || !workspace || !out || !out_f) return -1;
+  return loss_fwd_impl(p, mse_sums, workspace, out, out_f, stream);
+}
+
+extern "C" int madiff_loss_bwd_seg(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64,
+                                   const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B,
+                                   int T, int A, int F, int act, int nout, int discrete, int segments, const float* mse_sums,
+                                   const double* out, const void* go, int go_f64, float* d_eps, float* d_pred,
+                                   hipStream_t stream) {
+  LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete, segments};
+  if (loss_check(p) || !mse_sums || !out || !go || !d_eps || !d_pred) return -1;
+  const long n = (long)B * T * A * F;
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, p, mse_sums, out, go, go_f64, d_eps, d_pred);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

@@ -32,6 +32,7 @@ _SIGS = {
     "madiff_gemm_tile_count": [],
     "madiff_gemm_tile_info": [_i, _vp, _vp, _vp],
     "madiff_gemm_dgrad_wt": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "madiff_gemm_dgrad_wt_add": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],
     "madiff_gemm_wgrad": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i,
                           _vp],
     "madiff_pack_weight": [_i, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
@@ -47,6 +48,9 @@ _SIGS = {
     "madiff_loss_fwd_static": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "madiff_loss_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp,
                         _vp],
+    "madiff_loss_fwd_seg": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "madiff_loss_bwd_seg": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp,
+                            _vp, _vp],
     "madiff_inv_pairs": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_unpack_output": [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "madiff_posterior_step": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp],

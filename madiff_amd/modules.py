@@ -10,6 +10,8 @@ Internally activations are channels-last ("cl") matrices [(sequence, time), pad3
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import List, Optional, Tuple
 
@@ -138,6 +140,9 @@ class Conv1dBlock(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # temporal.py
 # ------------------------------------------------------------------------------------------------
+RES_BLOCK_NODE = os.environ.get("MADIFF_RES_BLOCK", "1") != "0"
+
+
 class ResidualTemporalBlock(nn.Module):
     """temporal.py:161-200.  keys: blocks.{0,1}.block.*, time_mlp.1.*, residual_conv.*"""
 
@@ -151,6 +156,13 @@ class ResidualTemporalBlock(nn.Module):
 
     def forward_cl(self, x, t, temb_proj, x2=None):
         """x cl [N*t, Cin]; temb_proj fp32 [N, >=Cout] = Linear(Mish(t_emb)) (computed by the fused time GEMM)."""
+        b0, b1 = self.blocks
+        if RES_BLOCK_NODE and b0.spec is CONV5 and b1.spec is CONV5:        # the whole block as one autograd node
+            rc = self.residual_conv if isinstance(self.residual_conv, nn.Conv1d) else None
+            return ops.res_block(x, x2, temb_proj, t, b0.n_groups,
+                                 (b0.block[0].weight, b0.block[0].bias, b0.block[2].weight, b0.block[2].bias),
+                                 (b1.block[0].weight, b1.block[0].bias, b1.block[2].weight, b1.block[2].bias),
+                                 None if rc is None else rc.weight, None if rc is None else rc.bias)
         h = self.blocks[0].forward_cl(x, t, x2=x2, rowbias=temb_proj)
         if isinstance(self.residual_conv, nn.Conv1d):
             res = conv_gemm(x, [self.residual_conv.weight], [self.residual_conv.bias], CONV1, t, x2=x2)

@@ -370,9 +370,14 @@ class GraphKernelTimer:
 GRAPH_TIMER: Optional[GraphKernelTimer] = None
 
 
+_ABLATE = frozenset(filter(None, os.environ.get("MADIFF_ABLATE", "").split(",")))
+
+
 def _timed(name: str, flops: float, launch, nbytes: float = 0.0, stream=None):
     """launch() may return the name of the kernel it actually dispatched to (overrides `name`).  `nbytes` = algorithmic
     HBM bytes of the launch (the HBM-bound families); `stream` = the stream the launch goes to when it is not the current one."""
+    if _ABLATE and name in _ABLATE:          # diagnostics only (scripts/ablate.sh): what does the step cost without this family?
+        return
     if TIMER is None:
         if GRAPH_TIMER is not None and torch.cuda.is_current_stream_capturing():
             GRAPH_TIMER.bracket(name, flops, launch, nbytes, stream)
@@ -466,9 +471,10 @@ def _gemm(x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, tr, W, nout, npad,
     return _tile_label(tile)
 
 
-def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncols, ncols_pad):
+def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncols, ncols_pad, addend=None):
     """Data gradient straight from the forward-layout bf16 weights (no transposed pack).  Returns the cl gradient
-    [M_in, ncols_pad], or None when the shape is not covered."""
+    [M_in, ncols_pad], or None when the shape is not covered.  addend (cl, same shape): merged in the kernel's epilogue
+    when the kernel offers it (_dgrad_wt.fused_add tells), else left to the caller."""
     # few output tiles + a long reduction (the time-MLP bundle: 1024 x 256 from K = 11520): slice the reduction
     blocks = -(-M_in // 64) * -(-ncols_pad // 128)
     nsteps = (npad // 64) * spec.taps
@@ -476,11 +482,16 @@ def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncol
     if blocks < 96 and nsteps >= 32:
         ksplit = max(1, min(nsteps // 8, 256 // blocks))
     gx = torch.empty(M_in, ncols_pad, dtype=torch.float32 if ksplit > 1 else act_dtype(), device=dy.device)
+    _dgrad_wt.fused_add = False
+    if addend is not None and (ksplit > 1 or addend.shape != (M_in, ncols_pad) or addend.dtype != act_dtype()
+                               or addend.stride(1) != 1):
+        addend = None
 
-    def launch(tile):
-        return lib.call_rc("madiff_gemm_dgrad_wt", dy.data_ptr(), dy.stride(0), M_in, npad, spec.taps, t_in, t_out,
+    def launch(tile, add=addend):
+        return lib.call_rc("madiff_gemm_dgrad_wt_add", dy.data_ptr(), dy.stride(0), M_in, npad, spec.taps, t_in, t_out,
                            spec.stride, spec.pad, 1 - spec.tr, Wf.data_ptr(), Wf.stride(0), wtap, wcol0, ncols,
-                           ncols_pad, gx.data_ptr(), gx.stride(0), tile, ksplit, _stream())
+                           ncols_pad, gx.data_ptr(), gx.stride(0), tile, ksplit, _p(add), 0 if add is None else add.stride(0),
+                           _stream())
 
     sig = ("wt", M_in, npad, spec.taps, ncols_pad, t_in, spec.stride, spec.tr)
     tile = _TUNE.get(sig)
@@ -488,14 +499,24 @@ def _dgrad_wt(dy, M_in, npad, spec: ConvSpec, t_in, t_out, Wf, wtap, wcol0, ncol
         return None
     if ksplit > 1 or tile is None:
         if launch(-1) != 0:          # probe = the real launch with the library's default variant
-            _TUNE[sig] = "uncovered"
-            return None
-        if ksplit <= 1:
-            _tuned_tile(sig, lib.tiles(wt=True), launch)   # remember the fastest variant (no-op under capture / if disabled)
+            if addend is None or launch(-1, None) != 0:
+                _TUNE[sig] = "uncovered"
+                return None
+            addend = None
+        if ksplit <= 1:              # remember the fastest variant (no-op under capture / if disabled)
+            _tuned_tile(sig, lib.tiles(wt=True), lambda t: launch(t, None))
+            if _TUNE.get(sig) is not None and addend is not None and launch(-1) != 0:
+                raise RuntimeError("madiff_gemm_dgrad_wt_add: the probed variant stopped covering this layer")
     elif launch(tile):
-        tile = -1
-        if launch(-1):
-            raise RuntimeError("madiff_gemm_dgrad_wt: no kernel variant covers this layer")
+        if addend is not None and launch(tile, None) == 0:
+            addend = None            # this variant has no vector epilogue here: the caller adds
+        else:
+            tile = -1
+            if launch(-1):
+                if addend is None or launch(-1, None):
+                    raise RuntimeError("madiff_gemm_dgrad_wt: no kernel variant covers this layer")
+                addend = None
+    _dgrad_wt.fused_add = addend is not None
     _dgrad_wt.last_label = _tile_label(tile)
     return gx.to(act_dtype()) if ksplit > 1 else gx
 
@@ -765,9 +786,10 @@ def _conv_forward(x, x2, rowbias, spec: ConvSpec, t_in: int, act: int, perm, wei
     return out, g
 
 
-def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bias_mode, need_rb):
+def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bias_mode, need_rb, addends=(None, None)):
     """dy: cl [M_out, pad32(osum)] in the storage dtype.  bias_mode: 'colsum' | 'none' (bias gradient produced
-    elsewhere, e.g. by the fused GroupNorm backward).  Returns (dx, dx2, drowbias, [gw], [gb])."""
+    elsewhere, e.g. by the fused GroupNorm backward).  addends = gradients of (x, x2) from another consumer, added to
+    dx / dx2 (in the data-gradient kernel's epilogue where it offers that).  Returns (dx, dx2, drowbias, [gw], [gb])."""
     spec, t_in, t_out, osum, cin, c1, n_seq, I = g.spec, g.t_in, g.t_out, g.osum, g.cin, g.c1, g.n_seq, g.I
     M, M_in, npad = n_seq * t_out, n_seq * t_in, pad32(osum)
     dx = dx2 = drb = None
@@ -779,19 +801,21 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
         if x2 is not None:
             parts.append((c1, I - c1, need_dx2))
         grads = []
-        for (row0, rows, need) in parts:
+        for (row0, rows, need), addend in zip(parts, addends):
             if not need:
                 grads.append(None)
                 continue
             res = [None]
+            fused_add = False
 
             def run_wt():
                 _dgrad_wt.last_label = None
-                res[0] = _dgrad_wt(dy, M_in, npad, spec, t_in, t_out, Wf, cin, row0, rows, pad32(rows))
+                res[0] = _dgrad_wt(dy, M_in, npad, spec, t_in, t_out, Wf, cin, row0, rows, pad32(rows), addend)
                 return _dgrad_wt.last_label
 
             if Wf is not None:
                 _timed("gemm_fwd_bf16_kernel", g.flops * rows / I, run_wt)
+                fused_add = res[0] is not None and _dgrad_wt.fused_add
             gx = res[0]
             if gx is None:
                 gx = torch.empty(M_in, pad32(rows), dtype=act_dtype(), device=dy.device)
@@ -802,6 +826,8 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
                     "madiff_gemm_fwd", _dt(), 0, dy.data_ptr(), dy.stride(0), None, 0, npad, M_in, npad, spec.taps,
                     t_in, t_out, spec.stride, spec.pad, 1 - spec.tr, Wb.data_ptr() + row0 * Wb.stride(0) * es,
                     Wb.stride(0), rows, pad32(rows), None, None, 0, gx.data_ptr(), gx.stride(0), 0, 0, 0, -1, _stream()))
+            if addend is not None and not fused_add:
+                gx = gx + addend
             grads.append(gx)
         dx = grads[0]
         if x2 is not None:
@@ -1085,6 +1111,68 @@ class ConvBlock(torch.autograd.Function):
         dy, dgamma, dbeta, dbias, drb, dres = _gn_backward(y, gamma, beta, stats, ctx.geom, dout, conv_bias=b)
         dx, dx2, _, gw, _ = _conv_backward(ctx.g, x, x2, [w], [b], dy, needs[0], needs[1], [needs[7]], "none", False)
         return (dx, dx2, drb, dres if ctx.geom[5] == 2 else None, None, None, None, gw[0], dbias, dgamma, dbeta)
+
+
+class ResBlock(torch.autograd.Function):
+    """ResidualTemporalBlock (temporal.py:161-200) as ONE autograd node:
+        h = Conv1dBlock0(x) + temb[n];  out = Conv1dBlock1(h) + residual_conv(x)
+    so that backward owns the order of its own launches: the input has two consumers (blocks[0] and residual_conv), and
+    instead of torch adding the two contributions in a separate pass, the residual one is handed to blocks[0]'s
+    data-gradient kernel as an addend.
+
+    apply(x, x2, temb, t_in, G, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb)   (rw / rb None: identity residual)"""
+
+    @staticmethod
+    def forward(ctx, x, x2, temb, t_in: int, G: int, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb):
+        need = any(ctx.needs_input_grad)
+
+        def block(xa, xb, rowbias, res, w, b, gamma, beta):
+            fused = _conv_block_fused(xa, xb, rowbias, res, CONV5, t_in, G, w, b, gamma, beta, need)
+            if fused is not None:
+                return fused
+            y, g = _conv_forward(xa, xb, None, CONV5, t_in, 0, None, [w], [b])
+            out, stats, geom = _gn_forward(y, gamma, beta, rowbias, res, g.n_seq, g.t_out, g.osum, G)
+            return out, y, stats, g, geom
+
+        h, y0, st0, cg0, geom0 = block(x, x2, temb, None, w0, b0, g0, be0)
+        if rw is not None:
+            res, cgr = _conv_forward(x, x2, None, CONV1, t_in, 0, None, [rw], [rb])
+        else:
+            assert x2 is None
+            res, cgr = x, None
+        out, y1, st1, cg1, geom1 = block(h, None, None, res, w1, b1, g1, be1)
+        ctx.save_for_backward(x, x2, y0, st0, h, y1, st1, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb)
+        ctx.geo = (cg0, geom0, cgr, cg1, geom1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, x2, y0, st0, h, y1, st1, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb = ctx.saved_tensors
+        cg0, geom0, cgr, cg1, geom1 = ctx.geo
+        needs = ctx.needs_input_grad
+        dout = dout.contiguous()
+        if dout.dtype != act_dtype():
+            dout = dout.to(act_dtype())
+        dy1, dgamma1, dbeta1, dbias1, _, _ = _gn_backward(y1, g1, be1, st1, geom1, dout, conv_bias=b1)
+        dh, _, _, gw1, _ = _conv_backward(cg1, h, None, [w1], [b1], dy1, True, False, [needs[9]], "none", False)
+        gwr, gbr = [None], [None]
+        if rw is not None:
+            dxr, dx2r, _, gwr, gbr = _conv_backward(cgr, x, x2, [rw], [rb], dout, needs[0], needs[1], [needs[13]], "colsum",
+                                                   False)
+        else:
+            dxr, dx2r = dout, None
+        dy0, dgamma0, dbeta0, dbias0, drb, _ = _gn_backward(y0, g0, be0, st0, geom0, dh, conv_bias=b0)
+        dx, dx2, _, gw0, _ = _conv_backward(cg0, x, x2, [w0], [b0], dy0, needs[0], needs[1], [needs[5]], "none", False,
+                                            addends=(dxr, dx2r))
+        return (dx, dx2, drb if needs[2] else None, None, None, gw0[0], dbias0, dgamma0, dbeta0, gw1[0], dbias1, dgamma1,
+                dbeta1, gwr[0], gbr[0])
+
+
+def res_block(x, x2, temb, t_in: int, G: int, blk0, blk1, rw=None, rb=None):
+    """blk0 / blk1 = (weight, bias, gamma, beta) of the two Conv1dBlocks."""
+    if x2 is not None and x.shape[1] % 128 != 0:   # the split-source kernels need 128-aligned halves
+        x, x2 = torch.cat((x, x2), dim=1), None
+    return ResBlock.apply(x, x2, temb, t_in, G, *blk0, *blk1, rw, rb)
 
 
 def conv_block(x, w, b, gamma, beta, spec: ConvSpec, t_in: int, G: int, x2=None, rowbias=None, res=None):

@@ -6,7 +6,8 @@ skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "mse_fwd_kernel" in r["Kernel_Name"]]
+mark = "loss_finish_kernel" if any("loss_finish_kernel" in r["Kernel_Name"] for r in rows) else "mse_fwd_kernel"
+marks = [i for i, r in enumerate(rows) if mark in r["Kernel_Name"]]
 lo, hi = marks[-2 - skip], marks[-1 - skip]
 t0 = int(rows[lo]["Start_Timestamp"])
 qs = {}
