@@ -436,15 +436,24 @@ class GaussianDiffusion(nn.Module):
         return inv_loss, info
 
     def loss(self, x, cond, loss_masks, attention_masks=None, returns=None, env_ts=None, states=None,
-             legal_actions=None, t=None, noise=None, dropout_mask=None):
-        """diffusion.py:438-496; called as ``loss(**batch)``."""
+             legal_actions=None, t=None, noise=None, dropout_mask=None, micro_batches: int = 1):
+        """diffusion.py:438-496; called as ``loss(**batch)``.
+
+        micro_batches = S > 1 (fused GPU loss only): the batch is S micro-batches of one optimizer step concatenated along
+        the batch axis; the returned loss is the mean of the S losses the reference's accumulation loop would compute
+        (training.py:147-152; the inverse-dynamics term is normalised per micro-batch), so ONE backward gives the
+        accumulated gradient.  info then holds the LAST micro-batch's values plus "micro_loss" = its loss."""
         # The inverse-dynamics branch shares nothing with the denoiser branch until the final sum, and it is a chain of
         # small launches: on the GPU it runs on a second stream (forward here, backward there too, since autograd replays
         # a node on its forward stream), i.e. as a parallel branch of the captured train-step graph.
         fused = (x.is_cuda and FUSED_LOSS and not self.train_only_inv and (self.share_inv or self.joint_inv)
                  and x.dtype == torch.float32 and loss_masks.dtype in (torch.float32, torch.float64))
         if fused:
-            return self._loss_fused(x, cond, loss_masks, returns, env_ts, legal_actions, t, noise, dropout_mask)
+            return self._loss_fused(x, cond, loss_masks, returns, env_ts, legal_actions, t, noise, dropout_mask,
+                                    int(micro_batches))
+        if micro_batches != 1:
+            raise NotImplementedError("micro_batches > 1 needs the fused GPU loss (share_inv or joint_inv, fp32 batch on the "
+                                      "GPU): call loss() once per micro-batch instead")
         side = None
         if x.is_cuda and not self.train_only_inv and INV_SIDE_STREAM:
             cur = torch.cuda.current_stream()
@@ -474,7 +483,7 @@ class GaussianDiffusion(nn.Module):
             return inv_loss, info
         return (1 / 2) * (diffuse_loss + inv_loss), info
 
-    def _loss_fused(self, x, cond, loss_masks, returns, env_ts, legal_actions, t, noise, dropout_mask):
+    def _loss_fused(self, x, cond, loss_masks, returns, env_ts, legal_actions, t, noise, dropout_mask, segments=1):
         """loss() for the shared / joint inverse-dynamics head on the GPU: the MLP's inputs come straight from the batch
         tensor (madiff_inv_pairs), its logits and the denoiser's epsilon go into ONE loss node (ops.FusedLoss: two launches
         forward, one backward) -- no ATen kernel between the two networks and the scalar loss."""
@@ -491,10 +500,14 @@ class GaussianDiffusion(nn.Module):
         epsilon, noise = self._predict_noise(x[..., self.action_dim:], cond, t, returns, env_ts, noise, dropout_mask)
         ops.wait_stream(cur, side)
         logits.record_stream(cur)
-        loss, a0, inv_loss, inv_acc = ops.FusedLoss.apply(
+        if B % segments:
+            raise ValueError(f"batch of {B} does not split into {segments} equal micro-batches")
+        loss, a0, inv_loss, inv_acc, last = ops.FusedLoss.apply(
             epsilon, noise, self.loss_fn.weights, loss_masks.reshape(B, T, A), logits, x, legal_actions,
-            (self.action_dim, nout, self.discrete_action, self.joint_inv))
+            (self.action_dim, nout, self.discrete_action, self.joint_inv, segments))
         info = {"a0_loss": a0}
+        if segments > 1:
+            info["micro_loss"] = last
         if self.discrete_action:
             info["inv_acc"] = inv_acc
         info["inv_loss"] = inv_loss

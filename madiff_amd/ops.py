@@ -1363,17 +1363,22 @@ class FusedLoss(torch.autograd.Function):
     launches forward and one backward.
 
     apply(eps [B,T,A,F], noise, w [T,A,F], loss_masks [B,T,A(,1)] fp64|fp32, pred fp32 [rows, ld], x [B,T,A,act+F],
-          legal [B,T,A,nout] | None, (act, nout, discrete, joint)) -> (loss, a0_loss, inv_loss, inv_acc)
-    loss / inv_loss / inv_acc take the dtype of loss_masks (the reference's promotion), a0_loss is fp32."""
+          legal [B,T,A,nout] | None, (act, nout, discrete, joint[, segments])) -> (loss, a0_loss, inv_loss, inv_acc, last_loss)
+    loss / inv_loss / inv_acc take the dtype of loss_masks (the reference's promotion), a0_loss is fp32.
+    segments = S > 1: the batch holds S micro-batches of one optimizer step; `loss` is the mean of their S losses (its
+    gradient = the accumulated gradient of training.py:147-152) while a0_loss / inv_loss / inv_acc / last_loss are the
+    LAST micro-batch's values, i.e. what the reference's loop has in hand when it logs."""
 
     @staticmethod
     def forward(ctx, eps, noise, w, masks, pred, x, legal, geom):
-        act, nout, discrete, joint = geom
+        act, nout, discrete, joint = geom[:4]
+        S = int(geom[4]) if len(geom) > 4 else 1
         B, T, A, F = eps.shape
         eps, noise, w, pred, x = eps.contiguous(), noise.contiguous(), w.contiguous(), pred.contiguous(), x.contiguous()
         masks = masks.contiguous()
         assert masks.dtype in (torch.float64, torch.float32) and masks.numel() == B * T * A
         assert eps.dtype == noise.dtype == pred.dtype == x.dtype == torch.float32 and x.shape == (B, T, A, act + F)
+        assert S >= 1 and B % S == 0
         if legal is not None:
             legal = legal.to(torch.float32).contiguous()
             assert legal.shape == (B, T, A, nout)
@@ -1386,31 +1391,32 @@ class FusedLoss(torch.autograd.Function):
             rs, as_ = A * ld, ld
         dev = eps.device
         sums = torch.empty(B, 3, dtype=torch.float32, device=dev)
-        ws = torch.empty(lib._lib.madiff_loss_ws_doubles(), dtype=torch.float64, device=dev)
-        out = torch.empty(6, dtype=torch.float64, device=dev)
-        out_f = torch.empty(6, dtype=torch.float32, device=dev)
+        ws = torch.empty(S * lib._lib.madiff_loss_ws_doubles(), dtype=torch.float64, device=dev)
+        out = torch.empty(6 * (1 + S), dtype=torch.float64, device=dev)
+        out_f = torch.empty(6 * (1 + S), dtype=torch.float32, device=dev)
         f64 = masks.dtype == torch.float64
-        lib.call("madiff_loss_fwd", eps.data_ptr(), noise.data_ptr(), w.data_ptr(), masks.data_ptr(), int(f64), pred.data_ptr(),
-                 rs, as_, x.data_ptr(), _p(legal), B, T, A, F, act, nout, int(discrete), sums.data_ptr(), ws.data_ptr(),
-                 out.data_ptr(), out_f.data_ptr(), _stream())
+        lib.call("madiff_loss_fwd_seg", eps.data_ptr(), noise.data_ptr(), w.data_ptr(), masks.data_ptr(), int(f64),
+                 pred.data_ptr(), rs, as_, x.data_ptr(), _p(legal), B, T, A, F, act, nout, int(discrete), S, sums.data_ptr(),
+                 ws.data_ptr(), out.data_ptr(), out_f.data_ptr(), _stream())
         ctx.save_for_backward(eps, noise, w, masks, pred, x, legal, sums, out)
-        ctx.geom = (B, T, A, F, act, nout, int(discrete), rs, as_, int(f64))
+        ctx.geom = (B, T, A, F, act, nout, int(discrete), rs, as_, int(f64), S)
         o = out if f64 else out_f
-        res = (o[0], out_f[1], o[2], o[3])
+        k = 6 * S if S > 1 else 0               # the last micro-batch's six (the only six when S == 1)
+        res = (o[0], out_f[k + 1], o[k + 2], o[k + 3], o[k])
         ctx.mark_non_differentiable(*res[1:])
         return res
 
     @staticmethod
     def backward(ctx, gl, *_unused):
         eps, noise, w, masks, pred, x, legal, sums, out = ctx.saved_tensors
-        B, T, A, F, act, nout, discrete, rs, as_, f64 = ctx.geom
+        B, T, A, F, act, nout, discrete, rs, as_, f64, S = ctx.geom
         if gl.dtype not in (torch.float32, torch.float64):
             gl = gl.to(torch.float32)
         gl = gl.contiguous()
         d_eps = torch.empty_like(eps)
         d_pred = torch.empty_like(pred)
-        lib.call("madiff_loss_bwd", eps.data_ptr(), noise.data_ptr(), w.data_ptr(), masks.data_ptr(), f64, pred.data_ptr(),
-                 rs, as_, x.data_ptr(), _p(legal), B, T, A, F, act, nout, discrete, sums.data_ptr(), out.data_ptr(),
+        lib.call("madiff_loss_bwd_seg", eps.data_ptr(), noise.data_ptr(), w.data_ptr(), masks.data_ptr(), f64, pred.data_ptr(),
+                 rs, as_, x.data_ptr(), _p(legal), B, T, A, F, act, nout, discrete, S, sums.data_ptr(), out.data_ptr(),
                  gl.data_ptr(), int(gl.dtype == torch.float64), d_eps.data_ptr(), d_pred.data_ptr(), _stream())
         return d_eps, None, None, None, d_pred, None, None, None
 

@@ -414,9 +414,47 @@ class FlatAdamEMA:
         ops.params_changed()
 
 
-def train_step(diffusion, opt: FlatAdamEMA, batches, do_ema: int = 0):
-    """One optimizer step over `len(batches)` micro-batches (training.py:147-158).  Returns the last (loss, infos)."""
+FOLD_MICRO_BATCHES = os.environ.get("MADIFF_FOLD_MICRO", "1") != "0"
+
+
+def can_fold(diffusion, batches) -> bool:
+    """May the micro-batches of one optimizer step run as ONE pass over their concatenation?  Needs the fused GPU loss
+    (it normalises the inverse-dynamics term per micro-batch, see GaussianDiffusion.loss(micro_batches=)) and equal sizes."""
+    from . import diffusion as D
+    if not FOLD_MICRO_BATCHES or len(batches) < 2 or len(batches) > 64 or not D.FUSED_LOSS:
+        return False
+    if getattr(diffusion, "train_only_inv", False) or not (getattr(diffusion, "share_inv", False)
+                                                           or getattr(diffusion, "joint_inv", False)):
+        return False
+    x0 = batches[0]["x"]
+    if not (x0.is_cuda and x0.dtype == torch.float32):
+        return False
+    keys = set(batches[0].keys())
+    return all(set(b.keys()) == keys and b["x"].shape == x0.shape for b in batches)
+
+
+def fold_batches(batches):
+    """Concatenate batch dicts (nested dicts of tensors) along the batch axis."""
+    def cat(vals):
+        if isinstance(vals[0], dict):
+            return {k: cat([v[k] for v in vals]) for k in vals[0]}
+        return torch.cat(vals, dim=0)
+    return {k: cat([b[k] for b in batches]) for k in batches[0]}
+
+
+def train_step(diffusion, opt: FlatAdamEMA, batches, do_ema: int = 0, fold: Optional[bool] = None):
+    """One optimizer step over `len(batches)` micro-batches (training.py:147-158).  Returns the last (loss, infos).
+    fold (default: when possible): one forward/backward over the concatenated micro-batches, same gradient."""
     n = len(batches)
+    if (fold is None or fold) and can_fold(diffusion, batches):
+        opt.set_sync(True)
+        opt.begin_step(do_ema)
+        loss, infos = diffusion.loss(**fold_batches(batches), micro_batches=n)
+        loss.backward()
+        opt.step(do_ema)
+        opt.zero_grad()
+        return infos.pop("micro_loss").detach(), infos
+    assert not fold, "these micro-batches cannot be folded (can_fold)"
     out = None
     for i, batch in enumerate(batches):
         opt.set_sync(i == n - 1)
@@ -446,7 +484,8 @@ class GraphedTrainStep:
     replayed backward pass, then the fused Adam/EMA launch follows eagerly.
     Call after at least one eager train_step (buffers materialised, GEMM variants tuned)."""
 
-    def __init__(self, diffusion, opt: FlatAdamEMA, example_batch, draws=None, warm_do_ema: int = 0):
+    def __init__(self, diffusion, opt: FlatAdamEMA, example_batch, draws=None, warm_do_ema: int = 0,
+                 fold: Optional[bool] = None):
         """example_batch: one batch dict, or a list of them = the micro-batches of one optimizer step (the reference's
         gradient_accumulate_every, training.py:147-152; each loss is scaled by 1/len before backward).
         draws = {"t", "noise", "dropout_mask"} (or one such dict per micro-batch) fixes the random draws of every
@@ -464,7 +503,19 @@ class GraphedTrainStep:
         self.draws = None if draws is None else [{k: v.clone() for k, v in d.items()} for d in draws]
         self.diffusion, self.opt = diffusion, opt
         clone = lambda v: {k: clone(u) for k, u in v.items()} if isinstance(v, dict) else v.clone()  # noqa: E731
-        self.batches = [clone(b) for b in examples]
+        # fold: the n micro-batches live in ONE concatenated static batch (self.big) and the step is one forward/backward
+        # over it (GaussianDiffusion.loss(micro_batches=n)): same gradient as n accumulated passes, a third of the launches
+        # at n = 2 -- what matters at the reference's own setting (batch 32 x accumulate 2), which is launch-latency bound
+        self.fold = n > 1 and (fold is None or fold) and can_fold(diffusion, examples)
+        assert not (fold and not self.fold), "these micro-batches cannot be folded (can_fold)"
+        if self.fold:
+            self.big = fold_batches(examples)
+            Bm = examples[0]["x"].shape[0]
+            view = lambda v, i: ({k: view(u, i) for k, u in v.items()} if isinstance(v, dict)      # noqa: E731
+                                 else v[i * Bm:(i + 1) * Bm])
+            self.batches = [view(self.big, i) for i in range(n)]
+        else:
+            self.batches = [clone(b) for b in examples]
         self.batch = self.batches[0]
         dev = opt.flat_p.device
         net = diffusion.model
@@ -505,7 +556,19 @@ class GraphedTrainStep:
 
     def _body(self, captured: bool = False):
         n = len(self.batches)
-        for i, batch in enumerate(self.batches):
+        if self.fold:
+            self.opt.set_sync(True)
+            if not captured:
+                self.opt.begin_step(self._warm_ema)
+            kw = dict(self.big)
+            kw.setdefault("dropout_mask", self.masks.view(n * self.masks.shape[1], *self.masks.shape[2:]))
+            if self.draws is not None:
+                kw["t"] = torch.cat([d["t"] for d in self.draws])
+                kw["noise"] = torch.cat([d["noise"] for d in self.draws])
+            loss, infos = self.diffusion.loss(**kw, micro_batches=n)
+            loss.backward()
+            loss = infos.pop("micro_loss")           # what the reference's loop logs: the last micro-batch's loss
+        for i, batch in enumerate(() if self.fold else self.batches):
             extra = {} if self.draws is None else {"t": self.draws[i]["t"], "noise": self.draws[i]["noise"]}
             self.opt.set_sync(i == n - 1)          # bucket hooks (all-reduce / optimizer slices): last micro-batch only
             if i == n - 1 and not captured:

@@ -1,0 +1,118 @@
+"""Micro-batch folding (the reference's gradient_accumulate_every, diffuser/utils/training.py:147-152): ONE pass over
+the concatenated micro-batches must give the accumulated gradient of S separate loss() calls each scaled by 1/S, with the
+inverse-dynamics term normalised by every micro-batch's own mask mean (diffuser/models/diffusion.py:407,418).  Checked
+against the oracle (per micro-batch) and against the unfolded HIP path."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import madiff_oracle as O
+from test_gpu_parity import SHAPES, T, build, prec  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _micro_batches(name, act, discrete, n, B, dev, ragged_masks=True):
+    from madiff_amd.host import batch_to_device
+    A, Tt, Fd, hh = SHAPES[name]
+    out = []
+    for i in range(n):
+        b = O.synthetic_batch(B, Tt, A, Fd, act, hh, discrete, 14 if discrete else 0, seed=40 + i)
+        if ragged_masks:          # different mask means per micro-batch: the per-micro-batch normalisation must show
+            lm = b["loss_masks"].clone()
+            lm[: 1 + i, Tt - (1 + (i % 2) if hh else 1 + 6 * i):] = 0
+            b["loss_masks"] = lm
+        out.append(batch_to_device(b, dev))
+    return out
+
+
+def _draws(n, B, A, Tt, Fd, K, dev):
+    g = torch.Generator().manual_seed(7)
+    return [{"t": torch.randint(0, K, (B,), generator=g).to(dev), "noise": torch.randn(B, Tt, A, Fd, generator=g).to(dev),
+             "dropout_mask": (torch.rand(B, A, 1, generator=g) < 0.75).float().to(dev)} for _ in range(n)]
+
+
+@pytest.mark.parametrize("name,discrete,share", [("spread", False, True), ("smac", True, True), ("tag", False, False)])
+def test_folded_loss_and_gradient_match_accumulation(prec, name, discrete, share):
+    from madiff_amd.trainer import fold_batches
+    dev = torch.device("cuda:0")
+    n, B = 3, 4
+    dif, act = build(name, 32, K=20, discrete=discrete, share_inv=share)
+    if not share:
+        dif2, _ = build(name, 32, K=20, discrete=discrete, share_inv=False)
+        with pytest.raises(NotImplementedError):
+            b = _micro_batches(name, act, discrete, 2, B, dev)
+            dif2.loss(**fold_batches(b), micro_batches=2)
+        return
+    A, Tt, Fd, hh = SHAPES[name]
+    mbs = _micro_batches(name, act, discrete, n, B, dev)
+    dr = _draws(n, B, A, Tt, Fd, 20, dev)
+    # unfolded: S calls, each scaled by 1/S (training.py:150-152)
+    losses, infos = [], None
+    for b, d in zip(mbs, dr):
+        loss, infos = dif.loss(**b, **d)
+        (loss / n).backward()
+        losses.append(loss.detach())
+    ref = {k: p.grad.clone() for k, p in dif.named_parameters() if p.grad is not None}
+    dif.zero_grad()
+    big = fold_batches(mbs)
+    loss, finfo = dif.loss(**big, t=torch.cat([d["t"] for d in dr]), noise=torch.cat([d["noise"] for d in dr]),
+                           dropout_mask=torch.cat([d["dropout_mask"] for d in dr]), micro_batches=n)
+    loss.backward()
+    tol = 1e-5 if prec == "fp32" else 2e-2
+    mean = torch.stack([l.double() for l in losses]).mean()
+    assert abs(float(loss) - float(mean)) < tol * abs(float(mean))
+    assert abs(float(finfo["micro_loss"]) - float(losses[-1])) < tol * abs(float(losses[-1]))
+    for k in ("a0_loss", "inv_loss") + (("inv_acc",) if discrete else ()):
+        assert abs(float(finfo[k]) - float(infos[k])) < tol * max(abs(float(infos[k])), 1e-3), k
+    # the micro-batches' mask means differ, so a whole-batch normalisation would be visibly off
+    whole, _ = dif.loss(**big, t=torch.cat([d["t"] for d in dr]), noise=torch.cat([d["noise"] for d in dr]),
+                        dropout_mask=torch.cat([d["dropout_mask"] for d in dr]))
+    if prec == "fp32" and hh == 0:
+        assert abs(float(whole) - float(mean)) > 1e-4 * abs(float(mean))
+    worst = 0.0
+    for k, p in dif.named_parameters():
+        if k not in ref:
+            continue
+        den = float(ref[k].abs().max())
+        if den < 1e-9:
+            continue
+        worst = max(worst, float((p.grad - ref[k]).abs().max()) / den)
+    # (bf16: GroupNorm statistics are per sample, so folding only reorders fp32 sums inside the weight-gradient GEMMs)
+    assert worst < (2e-4 if prec == "fp32" else 6e-2), worst
+
+
+def test_graphed_step_folds_and_matches_unfolded_steps(prec):
+    from madiff_amd import ops
+    from madiff_amd.trainer import FlatAdamEMA, GraphedTrainStep, train_step
+    dev = torch.device("cuda:0")
+    name, n, B = "spread", 2, 4
+    A, Tt, Fd, hh = SHAPES[name]
+    mbs = _micro_batches(name, 5, False, n, B, dev)
+    dr = _draws(n, B, A, Tt, Fd, 20, dev)
+    res = {}
+    for fold in (False, True):
+        dif, act = build(name, 32, K=20)
+        ema = copy.deepcopy(dif)
+        opt = FlatAdamEMA(dif, ema, lr=1e-3, ema_decay=0.9)
+        with_draws = [{**b, **d} for b, d in zip(mbs, dr)]
+        train_step(dif, opt, with_draws, do_ema=1, fold=fold)
+        g = GraphedTrainStep(dif, opt, mbs, draws=dr, fold=fold)
+        assert g.fold == fold
+        for i in range(3):
+            loss, infos = g.step(mbs, do_ema=1 if i == 2 else 0)
+        torch.cuda.synchronize()
+        res[fold] = (float(loss), {k: float(v) for k, v in infos.items()}, opt.flat_p.clone(), opt.flat_ema.clone())
+        ops.SINK = None
+    tol = 1e-5 if prec == "fp32" else 2e-2
+    assert abs(res[True][0] - res[False][0]) < tol * abs(res[False][0])
+    for k, v in res[False][1].items():
+        assert abs(res[True][1][k] - v) < tol * max(abs(v), 1e-3), k
+    # five Adam steps of lr 1e-3 move a parameter by <= 5e-3.  Adam normalises the gradient, so an element whose gradient is
+    # rounding noise may step either way: the bound on the worst element is loose, the bound on the mean is tight
+    for j in (2, 3):
+        d = (res[True][j] - res[False][j]).abs()
+        assert float(d.max()) < (5e-4 if prec == "fp32" else 5e-3), float(d.max())
+        assert float(d.mean()) < (2e-6 if prec == "fp32" else 2e-4), float(d.mean())
