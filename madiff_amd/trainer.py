@@ -29,11 +29,18 @@ from . import lib, ops
 class FlatAdamEMA:
     def __init__(self, module: torch.nn.Module, ema_module: Optional[torch.nn.Module] = None, lr: float = 2e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, ema_decay: float = 0.995, bucket_mb: float = 64.0,
-                 process_group=None, use_hip_kernel: Optional[bool] = None):
+                 process_group=None, use_hip_kernel: Optional[bool] = None, bucket_dtype: Optional[str] = None):
         self.module, self.ema_module = module, ema_module
         self.lr, self.betas, self.eps, self.ema_decay = lr, betas, eps, ema_decay
         self.step_count = 0
         self.bucket_bytes = int(bucket_mb * 2 ** 20)
+        # gradient transport: "fp32" (default: the all-reduce sums the flat fp32 gradient in place) or "bf16" (each bucket is
+        # rounded to bf16 into a staging buffer, all-reduced there -- half the bytes on the wire -- and written back into the
+        # fp32 master gradient; Adam, its moments and the weights stay fp32).  Lossy (8 mantissa bits per addend), off by default.
+        self.bucket_dtype = bucket_dtype or os.environ.get("MADIFF_BUCKET_DTYPE", "fp32")
+        if self.bucket_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"bucket_dtype must be 'fp32' or 'bf16', not {self.bucket_dtype!r}")
+        self._stage16 = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         # dp: the bucketed all-reduce machinery is active (MADIFF_FORCE_DP=1 keeps it on in a 1-rank group: tests)
@@ -230,6 +237,24 @@ class FlatAdamEMA:
             ops.wait_stream(tgt, st)
         ops.join_aux_streams(tgt)
 
+    def _reduce_begin(self, lo: int, hi: int):
+        """Start the all-reduce of flat_g[lo:hi) on the current stream; returns the work handle."""
+        g = self.flat_g[lo:hi]
+        if self.bucket_dtype == "bf16":
+            if self._stage16 is None:
+                self._stage16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.flat_g.device)
+            st = self._stage16[lo:hi]
+            st.copy_(g)                                   # fp32 -> bf16 (round to nearest even)
+            return dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _reduce_end(self, work, lo: int, hi: int):
+        """Order the current stream behind the collective (no host wait on the GPU) and, for bf16 transport, bring the sum
+        back into the fp32 master gradient."""
+        work.wait()
+        if self.bucket_dtype == "bf16":
+            self.flat_g[lo:hi].copy_(self._stage16[lo:hi])
+
     def _launch_bucket(self, b):
         if not self.dp:
             # single process: nothing to reduce; the bucket's optimizer slice goes onto the "wgrad" branch
@@ -257,17 +282,16 @@ class FlatAdamEMA:
             self._graph_order.append(bi)
             b["work"] = "graph"
             return
-        g = self.flat_g[b["lo"]:b["hi"]]
         if self._comm_stream is not None:
             self._order_behind_producers(self._comm_stream)   # members may have been produced on a side branch
             with torch.cuda.stream(self._comm_stream):
-                b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                b["work"] = self._reduce_begin(b["lo"], b["hi"])
                 if self._announced is not None and self.use_hip and self.overlap and ops.TIMER is None:
-                    b["work"].wait()          # orders the communication stream behind the collective (no host wait)
+                    self._reduce_end(b["work"], b["lo"], b["hi"])
                     self._adam_slice(b["lo"], b["hi"], *self._announced, self._comm_stream)
                     b["work"], b["opt"] = "done", True
         else:
-            b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            b["work"] = self._reduce_begin(b["lo"], b["hi"])
 
     # ------------------------------------------------------------------ per-step API
     def zero_grad(self):
@@ -320,8 +344,7 @@ class FlatAdamEMA:
             for bi in self._graph_order:
                 b = self.buckets[bi]
                 lib.call("madiff_stream_wait_event", cs.cuda_stream, self._graph_events[bi])
-                w = dist.all_reduce(self.flat_g[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                w.wait()
+                self._reduce_end(self._reduce_begin(b["lo"], b["hi"]), b["lo"], b["hi"])
                 if fused:
                     self._adam_slice(b["lo"], b["hi"], do_ema, None, cs)
                     b["opt"] = True
@@ -334,7 +357,7 @@ class FlatAdamEMA:
         if not self.dp:
             return
         if not self._hooks:            # first step: buffers were created after backward -> reduce everything now
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+            self._reduce_end(self._reduce_begin(0, self.total), 0, self.total)
             return
         for b in self.buckets:
             if b["work"] == "done":    # reduced by allreduce_after_replay()
@@ -342,7 +365,11 @@ class FlatAdamEMA:
             if b["work"] is None:      # a bucket whose hooks did not all fire (should not happen) -> reduce now
                 self._launch_bucket(b)
             if b["work"] != "done":
-                b["work"].wait()
+                if self._comm_stream is not None:
+                    with torch.cuda.stream(self._comm_stream):
+                        self._reduce_end(b["work"], b["lo"], b["hi"])
+                else:
+                    self._reduce_end(b["work"], b["lo"], b["hi"])
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 

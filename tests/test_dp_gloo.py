@@ -33,7 +33,7 @@ def _data(rank_slice=None):
     return x, y
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, bucket_dtype=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from madiff_amd.trainer import FlatAdamEMA
@@ -42,7 +42,7 @@ def _run(rank, world, port, out):
     import copy
     m = _model()
     ema = copy.deepcopy(m)
-    opt = FlatAdamEMA(m, ema, lr=1e-2, bucket_mb=0.0005, use_hip_kernel=False)
+    opt = FlatAdamEMA(m, ema, lr=1e-2, bucket_mb=0.0005, use_hip_kernel=False, bucket_dtype=bucket_dtype)
     opt.broadcast_parameters(0)
     x, y = _data()
     half = slice(0, 4) if rank == 0 else slice(4, 8)
@@ -55,6 +55,8 @@ def _run(rank, world, port, out):
         opt.zero_grad()
     assert len(opt.buckets) > 2
     assert m.unused.weight.grad is None
+    if bucket_dtype == "bf16":
+        assert opt._stage16 is not None and opt._stage16.dtype == torch.bfloat16 and opt.flat_g.dtype == torch.float32
     out[rank] = {k: v.detach().clone() for k, v in list(m.state_dict().items()) + [("ema." + k, v) for k, v in ema.state_dict().items()]}
     dist.destroy_process_group()
 
@@ -94,3 +96,26 @@ def test_two_rank_gloo_matches_single_process():
         o2.zero_grad()
     for k, v in m2.state_dict().items():
         assert torch.allclose(ref[k], v, rtol=1e-5, atol=1e-6), k
+
+
+def test_two_rank_gloo_bf16_gradient_transport():
+    """bucket_dtype="bf16": buckets travel as bf16 and come back into the fp32 master gradient.  Ranks stay bit-identical
+    (they apply the same reduced values); against the fp32 transport the FIRST-step gradient differs by bf16 rounding
+    (2^-9 relative per addend), which Adam turns into parameter differences far below one step (lr = 1e-2)."""
+    mgr = mp.get_context("spawn").Manager()
+    out16, out32 = mgr.dict(), mgr.dict()
+    port = 29000 + os.getpid() % 400
+    mp.spawn(_run, args=(2, port, out16, "bf16"), nprocs=2, join=True)
+    mp.spawn(_run, args=(2, port + 1, out32, None), nprocs=2, join=True)
+    a, b, ref = out16[0], out16[1], out32[0]
+    worst = 0.0
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        worst = max(worst, float((a[k] - ref[k]).abs().max()))
+    assert 0.0 < worst < 2e-3, worst          # not identical to fp32 transport, and well inside 2 steps x lr
+
+
+def test_bucket_dtype_is_validated():
+    from madiff_amd.trainer import FlatAdamEMA
+    with pytest.raises(ValueError):
+        FlatAdamEMA(_model(), None, bucket_dtype="fp8")
