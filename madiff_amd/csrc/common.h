@@ -43,6 +43,20 @@ __device__ __forceinline__ float mish_grad_f(float x) {
   return th + x * sig * (2.f * r) * (1.f + th);
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (id % 8), each with its own L2.  With the natural (x, y) -> tile map
+// every XCD then touches all tiles of one operand; this remap hands each XCD a compact (gx/4) x (gy/2) block of tiles
+// instead, so what its L2 fetches from HBM is a quarter of one operand plus half of the other.  Identity when the grid does
+// not divide (gx % 4, gy % 2); MADIFF_XCD_REMAP=0 switches it off through the `on` argument.
+__device__ __forceinline__ void xcd_remap(int& bx, int& by, int on) {
+  const int gx = gridDim.x, gy = gridDim.y;
+  if (!on || (gx & 3) || (gy & 1)) return;
+  const int id = bx + gx * by;
+  const int xcd = id & 7, local = id >> 3;
+  const int bw = gx >> 2, bh = gy >> 1;
+  bx = (xcd & 3) * bw + local % bw;
+  by = (xcd >> 2) * bh + local / bw;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

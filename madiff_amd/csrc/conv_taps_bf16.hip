@@ -78,7 +78,9 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int T = p.rm.T_out;
-  const int m0 = blockIdx.x * rows_used, n0 = blockIdx.y * 128;
+  int bx = blockIdx.x, by = blockIdx.y;
+  xcd_remap(bx, by, p.xcd);
+  const int m0 = bx * rows_used, n0 = by * 128;
 
   for (int i = tid; i < 512; i += NT) ((float*)(smem + (i >> 8) * A_BYTES + A_TILE))[i & 255] = 0.f;   // zero rows
 
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
     for (int e = 0; e < 8; e++) { gmv[e] = ge.gamma[c0 + e]; btv[e] = ge.beta[c0 + e]; }
 #pragma unroll
     for (int sl = 0; sl < SEQ; sl++) {
-      const int sq = wave + sl * NW, n = blockIdx.x * spt + sq;
+      const int sq = wave + sl * NW, n = bx * spt + sq;
       const bool live = sq < spt && n < n_seq;
 #pragma unroll
       for (int e = 0; e < 8; e++) rb[sl][e] = (live && ge.mode == 1) ? ge.rowbias[(size_t)n * ge.ldrb + c0 + e] : 0.f;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
     float sum[SEQ], sqs[SEQ], mean[SEQ], rstd[SEQ];
 #pragma unroll
     for (int sl = 0; sl < SEQ; sl++) {
-      const int sq = wave + sl * NW, n = blockIdx.x * spt + sq;
+      const int sq = wave + sl * NW, n = bx * spt + sq;
       const bool live = sq < spt && n < n_seq;
       sum[sl] = 0.f;
 #pragma unroll
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       sum[sl] += __shfl_xor(sum[sl], 16, 64);
       sum[sl] += __shfl_xor(sum[sl], 32, 64);
       mean[sl] = sum[sl] * inv_e;
-      const int sq = wave + sl * NW, n = blockIdx.x * spt + sq;
+      const int sq = wave + sl * NW, n = bx * spt + sq;
       const bool live = sq < spt && n < n_seq;
       sqs[sl] = 0.f;
 #pragma unroll
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       sqs[sl] += __shfl_xor(sqs[sl], 16, 64);
       sqs[sl] += __shfl_xor(sqs[sl], 32, 64);
       rstd[sl] = rsqrtf(sqs[sl] * inv_e + ge.eps);
-      const int sq = wave + sl * NW, n = blockIdx.x * spt + sq;
+      const int sq = wave + sl * NW, n = bx * spt + sq;
       const bool live = sq < spt && n < n_seq;
       if (!live) continue;
       if (ge.mean && r0 == 0 && (cv & ((1 << ge.gv_log2) - 1)) == 0) {

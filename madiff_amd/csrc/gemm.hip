@@ -386,6 +386,12 @@ static int pick_tile(int M, int Npad, int wt) {
   return best >= 1 ? best + 6 : best;      // three LDS stages for every shape but 128x128 (one workgroup per CU there)
 }
 
+static int xcd_on() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MADIFF_XCD_REMAP"); v = e ? (atoi(e) != 0) : 1; }
+  return v;
+}
+
 extern "C" int madiff_gemm_tile_count(void) { return kNumTiles; }
 // rows / columns / LDS stages of kernel variant `tile`; returns 1 when the variant also exists for the transposed-weight
 // data-gradient kernel (madiff_gemm_dgrad_wt), 0 when not, -1 for an invalid id
@@ -417,7 +423,7 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Npad; p.bias = bias; p.rowbias = rowbias; p.ldrb = ldrb;
   p.C = C; p.ldc = ldc; p.act = act; p.permT = permT; p.permA = permA;
-  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.addend = nullptr; p.lda = 0;
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on();
   dim3 grid((M + 127) / 128, (Npad + 127) / 128), block(256);
   if (tile >= kFirstTapsTile) {
     if (dtype != MADIFF_BF16 || !use_dma_kernel()) return 1;
@@ -456,7 +462,7 @@ extern "C" int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, i
   p.rm = RowMap{T, T, 1, 2, 0};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Nout; p.bias = bias; p.rowbias = nullptr; p.ldrb = 0;
   p.C = Y; p.ldc = ldy; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0;
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on();
   return madiff_launch_conv_taps_gn_bf16(&p, variant, out, ldo, gamma, beta, mean, rstd, G, eps, mode, rowbias, ldrb, res,
                                          ldr, Y != nullptr, stream);
 }
@@ -501,7 +507,7 @@ extern "C" int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred
   p.W = (const unsigned char*)W + (size_t)wcol0 * 2; p.ldw = ldw; p.Nout = Ncols; p.Npad = Npad;
   p.bias = nullptr; p.rowbias = nullptr; p.ldrb = 0;
   p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0; p.addend = addend; p.lda = ld_add;
+  p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0; p.addend = addend; p.lda = ld_add; p.xcd = xcd_on();
   const int nsteps = (Kred / 64) * taps;
   p.ksplit = ksplit > 1 ? (ksplit < nsteps ? ksplit : nsteps) : 0;
   if (p.ksplit > 1) {
@@ -528,7 +534,7 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
   GemmWgradParams p;
   p.dY = dY; p.ldy = ldy; p.Ycols = Ycols; p.X = X; p.ldx = ldx; p.X2 = X2; p.ldx2 = ldx2; p.Csplit = Csplit;
   p.M = M; p.Cin = Cin; p.taps = taps; p.rm = RowMap{T_out, T_in, stride, pad, tr};
-  p.dW = dW; p.ldw = ldw; p.Nout = Nout; p.accumulate = accumulate ? 1 : 0;
+  p.dW = dW; p.ldw = ldw; p.Nout = Nout; p.accumulate = accumulate ? 1 : 0; p.xcd = xcd_on();
   const bool dma = dtype == MADIFF_BF16 && use_dma_kernel() && T_out < 256 && M < (1 << 24);
   // all-taps kernel (variants 4..7): stride-1 "same" k5 convolutions whose sequence length divides 32 or 96 rows
   const int nq = (32 % T_out == 0) ? 1 : ((96 % T_out == 0) ? 3 : 0);

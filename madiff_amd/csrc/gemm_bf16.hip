@@ -564,7 +564,9 @@ __global__ __launch_bounds__(256, (BO >= 128 ? 1 : 2)) void gemm_wgrad_taps_bf16
   __shared__ __attribute__((aligned(1024))) unsigned char smem[D * BUF_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wc = wave & 1;
-  const int n0 = blockIdx.x * BO, c0 = blockIdx.y * BC;
+  int bx = blockIdx.x, by = blockIdx.y;
+  xcd_remap(bx, by, p.xcd);
+  const int n0 = bx * BO, c0 = by * BC;
   const int T = p.rm.T_out, pad = p.rm.pad;
   const int total_steps = (p.M + KR - 1) / KR;
   const int s_begin = blockIdx.z * p.steps_per_split;
@@ -749,7 +751,9 @@ __global__ __launch_bounds__(512) void gemm_wgrad_taps8_bf16_kernel(GemmWgradPar
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2, w4 = wave & 3;
   const int wn = w4 >> 1, wc = w4 & 1;
-  const int n0 = blockIdx.x * BO, c0 = blockIdx.y * BC;
+  int bx = blockIdx.x, by = blockIdx.y;
+  xcd_remap(bx, by, p.xcd);
+  const int n0 = bx * BO, c0 = by * BC;
   const int T = p.rm.T_out, pad = p.rm.pad;
   const int total_steps = (p.M + KR - 1) / KR;
   const int s_begin = blockIdx.z * p.steps_per_split;

@@ -27,6 +27,7 @@ struct GemmFwdParams {
   int vec_epi;                       // 1: pointers/strides allow the 16-byte vector epilogue (set by the launcher)
   int ksplit;                        // > 1: gridDim.z slices of the K-steps combine with fp32 atomics (fp32 C, pre-zeroed)
   const void* addend; int lda;       // bf16 [M, lda] added to the result after the activation (vector epilogues only), or null
+  int xcd;                           // 1: XCD-aware workgroup -> tile map (common.h xcd_remap), all-taps kernel
 };
 
 struct GemmWgradParams {
@@ -41,6 +42,7 @@ struct GemmWgradParams {
   int ctiles;                             // ceil(Cin / 128)
   int steps_per_split, splits;            // reduction steps (KR rows each) per z-slice
   int accumulate;                         // 1: dW += result (dW is a live gradient buffer), 0: dW = result
+  int xcd;                                // 1: XCD-aware workgroup -> tile map (all-taps kernels)
 };
 
 __device__ __forceinline__ int map_row(int n, int t, int tap, const RowMap& rm) {

@@ -19,7 +19,9 @@ def collect(counter):
     return rows
 out = {}
 fam = lambda n: re.sub(r"^void ", "", n).split("<")[0].split("(")[0]
-FAMS = ("conv_taps_bf16_kernel", "gemm_fwd_bf16_kernel", "gemm_wgrad_taps_bf16_kernel", "gemm_wgrad_bf16_kernel")
+FAMS = ("conv_taps_bf16_kernel", "gemm_fwd_bf16_kernel", "gemm_wgrad_taps8_bf16_kernel", "gemm_wgrad_taps_bf16_kernel",
+        "gemm_wgrad_bf16_kernel", "gn_mish_bwd_rb_kernel", "gn_mish_fwd_rb_kernel", "adam_ema_kernel", "attn_fwd_v2_kernel",
+        "attn_bwd_v2_kernel")
 def family(name):
     for f in FAMS:
         if f in name:
@@ -28,7 +30,7 @@ def family(name):
 res = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = collect(counter)
-    adam = [i for i, r in enumerate(rows) if "mse_fwd_kernel" in r["Kernel_Name"]]   # one per optimizer step
+    adam = [i for i, r in enumerate(rows) if "loss_finish_kernel" in r["Kernel_Name"]]   # one per optimizer step
     lo, hi = adam[-3] + 1, adam[-1] + 1            # the last two optimizer steps (steady state, after autotuning)
     for r in rows[lo:hi]:
         f = family(r["Kernel_Name"])
