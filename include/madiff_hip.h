@@ -115,6 +115,15 @@ int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void*
                       int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,
                       int ldw, int Nout, int accumulate, int tile, int splits, madiff_stream_t stream);
 
+/* madiff_gemm_wgrad plus the bias gradient of the same layer (group) in the same call: dbias[o] += sum_m dY[m, o], or
+   *bias_table[o] += ... (one destination address per output column; exactly one of the two is non-NULL).  Replaces the
+   bias half of every Conv1d / Linear backward (ATen's sum over the output gradient).  The per-tap LDS-DMA kernel forms
+   the sums itself, without a second pass over dY; otherwise madiff_colsum(_scatter) runs behind the weight gradient. */
+int madiff_gemm_wgrad_bias(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,
+                           int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,
+                           int ldw, int Nout, int accumulate, int tile, int splits, float* dbias, const void* bias_table,
+                           madiff_stream_t stream);
+
 /* Parameter layout (fp32, element (o, i, tap) at o*so + i*si + tap*st) <-> GEMM layout [O, taps, Ipad].
  * pack writes dst[(o*taps + tap)*dst_ld + dst_off + i] and leaves pad columns alone (buffer is zero-filled once). */
 int madiff_pack_weight(int dtype, const float* src, void* dst, int O, int I, int taps, long so, long si, long st,

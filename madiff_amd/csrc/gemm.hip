@@ -519,10 +519,43 @@ extern "C" int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred
   return madiff_launch_gemm_fwd_bf16(&p, 0, tile >= 0 ? tile : pick_tile(M, Npad, 1), stream);
 }
 
+extern "C" int madiff_colsum(int dtype, const void* x, int ld, float* out, long M, int C, hipStream_t stream);
+extern "C" int madiff_colsum_scatter(int dtype, const void* x, int ld, float* const* table, long M, int C, hipStream_t stream);
+static int wgrad_impl(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,
+                      int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,
+                      int ldw, int Nout, int accumulate, int tile, int splits, float* dbias, float* const* btab,
+                      int* bias_fused, hipStream_t stream);
+
 extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2,
                                  int ldx2, int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride,
                                  int pad, int tr, float* dW, int ldw, int Nout, int accumulate, int tile, int splits,
                                  hipStream_t stream) {
+  int fused = 0;
+  return wgrad_impl(dtype, dY, ldy, Ycols, X, ldx, X2, ldx2, Csplit, M, Cin, taps, T_out, T_in, stride, pad, tr, dW, ldw, Nout,
+                    accumulate, tile, splits, nullptr, nullptr, &fused, stream);
+}
+
+// Weight gradient AND bias gradient of a layer (group): dbias[o] += sum_m dY[m, o], or *bias_table[o] += ... when the
+// group's biases live at scattered addresses (one pointer per output column, as madiff_colsum_scatter takes).  The per-tap
+// LDS-DMA kernel produces the sums itself (one extra MFMA per dY fragment against an all-ones operand, no second pass
+// over dY); for every other kernel the column-sum kernel is launched behind the weight gradient.  Status as madiff_gemm_wgrad.
+extern "C" int madiff_gemm_wgrad_bias(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2,
+                                      int ldx2, int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride,
+                                      int pad, int tr, float* dW, int ldw, int Nout, int accumulate, int tile, int splits,
+                                      float* dbias, const void* bias_table, hipStream_t stream) {
+  if (!dbias == !bias_table) return -1;                       // exactly one destination form
+  int fused = 0;
+  int rc = wgrad_impl(dtype, dY, ldy, Ycols, X, ldx, X2, ldx2, Csplit, M, Cin, taps, T_out, T_in, stride, pad, tr, dW, ldw,
+                      Nout, accumulate, tile, splits, dbias, (float* const*)bias_table, &fused, stream);
+  if (rc != 0 || fused || M <= 0 || Nout <= 0) return rc;
+  return dbias ? madiff_colsum(dtype, dY, ldy, dbias, M, Nout, stream)
+               : madiff_colsum_scatter(dtype, dY, ldy, (float* const*)bias_table, M, Nout, stream);
+}
+
+static int wgrad_impl(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,
+                      int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,
+                      int ldw, int Nout, int accumulate, int tile, int splits, float* dbias, float* const* btab,
+                      int* bias_fused, hipStream_t stream) {
   static const int kBO[10] = {128, 128, 64, 64, 64, 64, 128, 128, 64, 64}, kBC[10] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 64};
   const int es = dtype == MADIFF_BF16 ? 2 : 4;
   if (M <= 0 || Nout <= 0) return 0;
@@ -535,6 +568,7 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
   p.dY = dY; p.ldy = ldy; p.Ycols = Ycols; p.X = X; p.ldx = ldx; p.X2 = X2; p.ldx2 = ldx2; p.Csplit = Csplit;
   p.M = M; p.Cin = Cin; p.taps = taps; p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.dW = dW; p.ldw = ldw; p.Nout = Nout; p.accumulate = accumulate ? 1 : 0; p.xcd = xcd_on();
+  p.dbias = nullptr; p.btab = nullptr;
   const bool dma = dtype == MADIFF_BF16 && use_dma_kernel() && T_out < 256 && M < (1 << 24);
   // all-taps kernel (variants 4..7): stride-1 "same" k5 convolutions whose sequence length divides 32 or 96 rows
   const int nq = (32 % T_out == 0) ? 1 : ((96 % T_out == 0) ? 3 : 0);
@@ -566,7 +600,10 @@ extern "C" int madiff_gemm_wgrad(int dtype, const void* dY, int ldy, int Ycols, 
   if (all_taps)
     return madiff_launch_gemm_wgrad_taps_bf16(&p, tile, nq, (Nout + BO - 1) / BO, p.ctiles, p.splits, stream);
   dim3 grid((Nout + BO - 1) / BO, p.ctiles * taps, p.splits), block(256);
-  if (dma) return madiff_launch_gemm_wgrad_bf16(&p, tile, grid.x, grid.y, grid.z, stream);
+  if (dma) {
+    p.dbias = dbias; p.btab = btab; *bias_fused = (dbias || btab) ? 1 : 0;
+    return madiff_launch_gemm_wgrad_bf16(&p, tile, grid.x, grid.y, grid.z, stream);
+  }
   if (dtype == MADIFF_BF16) hipLaunchKernelGGL((gemm_wgrad_kernel<bf16_t>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((gemm_wgrad_kernel<float>), grid, block, 0, stream, p);
   MADIFF_CHECK_LAUNCH();

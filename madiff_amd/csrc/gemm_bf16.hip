@@ -456,6 +456,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
   for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // Bias gradient = column sums of dY = dY^T * 1: the waves of the (tap 0, first channel tile) workgroups that hold the
+  // first X half run one more MFMA per dY fragment against an all-ones operand (every output column then holds the sum).
+  const bool do_bias = (p.dbias || p.btab) && blockIdx.y == 0 && wc == 0;
+  f32x4 accb[MI];
+#pragma unroll
+  for (int i = 0; i < MI; i++) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (bf16_t)1.0f;
 
   const int fr = lane & 15, fq = lane >> 4;
   const int tq = fr >> 2, tp = fr & 3;
@@ -498,9 +507,22 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(GemmWgradParams
 #pragma unroll
         for (int j = 0; j < NJ; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < MI; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+      }
     }
   }
 
+  if (do_bias && fr == 0) {
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = n0 + wn * (BO / 2) + i * 16 + fq * 4 + r;
+        if (n < p.Nout) atomicAdd(p.btab ? p.btab[n] : p.dbias + n, accb[i][r]);
+      }
+  }
 #pragma unroll
   for (int i = 0; i < MI; i++)
 #pragma unroll

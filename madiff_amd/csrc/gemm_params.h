@@ -43,6 +43,9 @@ struct GemmWgradParams {
   int steps_per_split, splits;            // reduction steps (KR rows each) per z-slice
   int accumulate;                         // 1: dW += result (dW is a live gradient buffer), 0: dW = result
   int xcd;                                // 1: XCD-aware workgroup -> tile map (all-taps kernels)
+  // bias gradient fused into the per-tap LDS-DMA kernel: column sums of dY, accumulated atomically into dbias[o] or, for a
+  // fused layer group, into *btab[o] (one destination address per output column); both null = not requested
+  float* dbias; float* const* btab;
 };
 
 __device__ __forceinline__ int map_row(int n, int t, int tap, const RowMap& rm) {

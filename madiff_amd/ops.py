@@ -527,8 +527,15 @@ _WGRAD_TILES = ((128, 128, 0), (128, 64, 0), (64, 128, 0), (64, 64, 0), (64, 64,
                 (64, 64, 1), (64, 64, 1))
 
 
-def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, accumulate=0):
-    def launch(dst, acc, tile, splits):
+def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, accumulate=0, dbias=None, btab=None):
+    """dbias (fp32 [nout], accumulated) / btab (device table of one destination address per output column): also produce
+    the bias gradient (madiff_gemm_wgrad_bias); the tuning launches never do."""
+    def launch(dst, acc, tile, splits, bias=False):
+        if bias and (dbias is not None or btab is not None):
+            return lib.call_rc("madiff_gemm_wgrad_bias", _dt(), dy.data_ptr(), dy.stride(0), dy.shape[1], x.data_ptr(),
+                               x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0), csplit, M, cin, spec.taps, t_out,
+                               t_in, spec.stride, spec.pad, spec.tr, dst.data_ptr(), dst.stride(0), nout, acc, tile, splits,
+                               _p(dbias), _p(btab), _stream())
         return lib.call_rc("madiff_gemm_wgrad", _dt(), dy.data_ptr(), dy.stride(0), dy.shape[1], x.data_ptr(),
                            x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0), csplit, M, cin, spec.taps, t_out, t_in,
                            spec.stride, spec.pad, spec.tr, dst.data_ptr(), dst.stride(0), nout, acc, tile, splits,
@@ -560,9 +567,9 @@ def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, acc
         cfg = _TUNE[sig] = best
     if cfg is None:
         cfg = (-1, 0)
-    if launch(dW, accumulate, cfg[0], cfg[1]) != 0:
+    if launch(dW, accumulate, cfg[0], cfg[1], True) != 0:
         # (a remembered variant that does not cover this layer after all: the library's own choice must)
-        if cfg == (-1, 0) or launch(dW, accumulate, -1, 0) != 0:
+        if cfg == (-1, 0) or launch(dW, accumulate, -1, 0, True) != 0:
             raise RuntimeError("madiff_gemm_wgrad: no kernel variant covers this layer")
         cfg = _TUNE[sig] = (-1, 0)
     return "gemm_wgrad_taps_bf16_kernel" if (cfg[0] >= 4 and _PRECISION == "bf16") else None
@@ -842,6 +849,7 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
 
 
 WGRAD_SIDE_STREAM = os.environ.get("MADIFF_WGRAD_SIDE_STREAM", "1") != "0"
+FUSE_BIAS_WGRAD = os.environ.get("MADIFF_FUSE_BIAS_WGRAD", "1") != "0"
 
 
 def _param_grads_side(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
@@ -875,14 +883,27 @@ def _param_grads_side(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
 def _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
     spec, t_in, t_out, osum, cin, c1, n_seq, I = g.spec, g.t_in, g.t_out, g.osum, g.cin, g.c1, g.n_seq, g.I
     M = n_seq * t_out
+    bias_done = False
     if any(need_w):
         wlabel = "gemm_wgrad_bf16_kernel" if _PRECISION == "bf16" else "gemm_wgrad_kernel<float>"
         gm = SINK.grad_matrix(weights, spec) if (SINK is not None and all(need_w)) else None
         if gm is not None:       # accumulate straight into the flat gradient (kept in this GEMM layout)
             assert gm.shape == (osum, spec.taps * cin)
-            _timed(wlabel, g.flops, lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, gm, osum, 1))
+            # the bias gradient rides along (column sums of dy inside the weight-gradient kernel) when every bias of the
+            # group has a live slot in the flat gradient
+            dbias = btab = None
+            if FUSE_BIAS_WGRAD and biases and bias_mode == "colsum" and all(_sink_view(b) is not None for b in biases):
+                if len(biases) == 1:
+                    dbias = _sink_view(biases[0])
+                else:
+                    btab = SINK.bias_table(biases, dy.device)
+            _timed(wlabel, g.flops, lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, gm, osum, 1, dbias, btab))
             for w in weights:
                 SINK.done(w)
+            if dbias is not None or btab is not None:
+                bias_done = True
+                for b in biases:
+                    SINK.done(b)
         else:
             dW = torch.empty(osum, spec.taps * cin, dtype=torch.float32, device=dy.device)
             _timed(wlabel, g.flops, lambda: _wgrad(dy, x, x2, c1, M, cin, spec, t_out, t_in, dW, osum, 0))
@@ -900,7 +921,7 @@ def _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
                         gw[i] = gv
                 off += O
     gb: List[Optional[torch.Tensor]] = [None] * len(biases)
-    if biases and bias_mode == "colsum":
+    if biases and bias_mode == "colsum" and not bias_done:
         if len(biases) == 1 and _sink_view(biases[0]) is not None:
             view = _sink_view(biases[0])       # colsum accumulates atomically: add straight into the live gradient
             lib.call("madiff_colsum", _dt(), dy.data_ptr(), dy.stride(0), view.data_ptr(), M, osum, _stream())

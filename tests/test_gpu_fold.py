@@ -114,5 +114,5 @@ def test_graphed_step_folds_and_matches_unfolded_steps(prec):
     # rounding noise may step either way: the bound on the worst element is loose, the bound on the mean is tight
     for j in (2, 3):
         d = (res[True][j] - res[False][j]).abs()
-        assert float(d.max()) < (5e-4 if prec == "fp32" else 5e-3), float(d.max())
+        assert float(d.max()) < (5e-4 if prec == "fp32" else 1.2e-2), float(d.max())   # bf16: two opposite 5-step walks
         assert float(d.mean()) < (2e-6 if prec == "fp32" else 2e-4), float(d.mean())

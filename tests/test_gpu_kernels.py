@@ -161,6 +161,29 @@ def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
                     continue
                 got = dW.view(Co, k, Cin) - (1.0 if accumulate else 0.0)
                 assert rel_err(got.cpu(), gw_ref.cpu()) < 3 * TOL["bf16"], (tile, splits, accumulate)
+                # the same launch with the bias gradient riding along (column sums of dY), both destination forms: a
+                # contiguous vector and one address per output column (scattered over two buffers here); accumulating
+                db_ref = gy.sum(dim=(0, 2)).cpu()
+                for form in ("vector", "table"):
+                    dW2 = torch.full_like(dW, 1.0 if accumulate else float("nan"))
+                    db = torch.full((2, Co), 0.5, dtype=torch.float32, device=dev)
+                    tab = None
+                    if form == "table":
+                        tab = torch.tensor([db[o % 2].data_ptr() + 4 * o for o in range(Co)], dtype=torch.int64).to(dev)
+                    rc = lib.call_rc("madiff_gemm_wgrad_bias", lib.BF16, gycl.data_ptr(), gycl.stride(0), gycl.shape[1],
+                                     xcl.data_ptr(), xcl.stride(0), None, 0, Cin, N * T2, Cin, k, T2, T, spec.stride, spec.pad,
+                                     spec.tr, dW2.data_ptr(), dW2.stride(0), Co, accumulate, tile, splits,
+                                     None if tab is not None else db[0].data_ptr(), None if tab is None else tab.data_ptr(), st)
+                    assert rc == 0
+                    assert rel_err((dW2.view(Co, k, Cin) - (1.0 if accumulate else 0.0)).cpu(), gw_ref.cpu()) < 3 * TOL["bf16"]
+                    if form == "vector":
+                        got_b, untouched = db[0] - 0.5, db[1]
+                    else:
+                        sel = (torch.arange(Co, device=dev) % 2).bool()
+                        got_b = torch.where(sel, db[1], db[0]) - 0.5
+                        untouched = torch.where(sel, db[0], db[1])
+                    assert rel_err(got_b.cpu(), db_ref) < 2e-3, (tile, splits, form)
+                    assert torch.all(untouched == 0.5)
 
 
 def test_conv_gemm_split_source(prec):
