@@ -421,6 +421,48 @@ def _tile_label(tile):
 _TUNE_BY_PRECISION: dict = {_PRECISION: {}}
 _TUNE: dict = _TUNE_BY_PRECISION[_PRECISION]
 _AUTOTUNE = os.environ.get("MADIFF_AUTOTUNE", "1") != "0"
+# MADIFF_TUNE_CACHE=<file>: kernel-variant choices (per build, keyed by layer shape) are read from the file at import and
+# written back at exit, so a later process starts without timing launches (and a profiler sees only the steady state).
+_TUNE_CACHE = os.environ.get("MADIFF_TUNE_CACHE")
+
+
+def load_tune_cache(path: str) -> int:
+    """Merge remembered variant choices from `path` (a file save_tune_cache wrote).  Returns the number of entries."""
+    import ast
+    import json
+    global _TUNE
+    with open(path) as f:
+        data = json.load(f)
+    if data.get("arch") != lib.arch() or data.get("version") != lib.version():
+        return 0                       # choices of another library build do not carry over
+    n = 0
+    for prec, entries in data.get("choices", {}).items():
+        d = _TUNE_BY_PRECISION.setdefault(prec, {})
+        for k, v in entries:
+            d[ast.literal_eval(k)] = tuple(v) if isinstance(v, list) else v
+            n += 1
+    _TUNE = _TUNE_BY_PRECISION.setdefault(_PRECISION, {})
+    return n
+
+
+def save_tune_cache(path: str) -> None:
+    import json
+    data = {"arch": lib.arch(), "version": lib.version(),
+            "choices": {prec: [[repr(k), v] for k, v in d.items()] for prec, d in _TUNE_BY_PRECISION.items() if d}}
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        json.dump(data, f)
+    os.replace(tmp, path)
+
+
+if _TUNE_CACHE:
+    import atexit
+    if os.path.exists(_TUNE_CACHE):
+        try:
+            load_tune_cache(_TUNE_CACHE)
+        except (OSError, ValueError, SyntaxError):
+            pass                       # unreadable cache: tune again
+    atexit.register(lambda: save_tune_cache(_TUNE_CACHE))
 
 
 def _tuned_tile(sig, candidates, launch) -> int:

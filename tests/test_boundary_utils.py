@@ -47,3 +47,23 @@ def test_config_builds_lazily():
     c = U.Config(torch.nn.Linear, in_features=3, out_features=5)
     assert dict(c) == {"in_features": 3, "out_features": 5} and c.in_features == 3
     assert c().weight.shape == (5, 3)
+
+
+def test_tune_cache_round_trip(tmp_path):
+    """Kernel-variant choices survive a save / load (keys are tuples of layer geometry, values ints / pairs / markers)."""
+    from madiff_amd import ops
+    saved = {p: dict(d) for p, d in ops._TUNE_BY_PRECISION.items()}
+    try:
+        ops._TUNE_BY_PRECISION.setdefault("bf16", {}).update({("fwd", 6144, 1024, 5, True): 15, ("wgrad", 6144, 64): (8, 1),
+                                                              ("wt", 12, 3): "uncovered"})
+        path = str(tmp_path / "tune.json")
+        ops.save_tune_cache(path)
+        for d in ops._TUNE_BY_PRECISION.values():
+            d.clear()
+        assert ops.load_tune_cache(path) >= 3
+        d = ops._TUNE_BY_PRECISION["bf16"]
+        assert d[("fwd", 6144, 1024, 5, True)] == 15 and d[("wgrad", 6144, 64)] == (8, 1) and d[("wt", 12, 3)] == "uncovered"
+    finally:
+        for p in list(ops._TUNE_BY_PRECISION):
+            ops._TUNE_BY_PRECISION[p].clear()
+            ops._TUNE_BY_PRECISION[p].update(saved.get(p, {}))
