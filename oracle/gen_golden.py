@@ -548,7 +548,71 @@ def gen_alternates(R):
     save("g9_alternates", **out)
 
 
+def gen_planner():
+    """g10: the evaluator's planning step, `MADEvaluatorWorker._generate_samples`
+    (utils/evaluator.py:39-135), called as a plain function on a stand-in `self` -- the reference's own mask generator
+    (utils/mask_generator.py) and array helpers (utils/arrays.py), a Config with the evaluator's fields and a recording
+    stand-in for `trainer.ema_model` whose conditional_sample returns a closed-form tensor.  Pins what the sampler is CALLED
+    with (conditioning trajectories and masks, the (b a) expansion of returns / env_ts, the env_ts clamp) and the gather
+    of the decentralized plans; the sampler itself is pinned elsewhere (g6).  ml_logger and launcher_util (params_proto)
+    are absent third-party / control-plane imports of evaluator.py and are stubbed; the environment loop is not run."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    mod("ml_logger", logger=types.SimpleNamespace(print=print))
+    d = mod("diffuser")
+    d.__path__ = [REF]
+    u = mod("diffuser.utils")
+    u.__path__ = [REF + "/utils"]
+    d.utils = u
+    load("diffuser.utils.arrays", REF + "/utils/arrays.py")
+    mod("diffuser.utils.launcher_util", build_config_from_dict=lambda specs, Config=None: types.SimpleNamespace(**specs))
+    mg = load("diffuser.utils.mask_generator", REF + "/utils/mask_generator.py")
+    ev = load("diffuser.utils.evaluator", REF + "/utils/evaluator.py")
+    out = {}
+    for tag, (A, horizon, hh, F, B, dec) in {"cen": (3, 6, 2, 4, 2, False), "dec": (3, 6, 2, 4, 2, True),
+                                             "dec_nohist": (2, 8, 0, 5, 3, True)}.items():
+        calls = []
+
+        class FakeEMA:
+            def conditional_sample(self, conditions, returns=None, env_ts=None, attention_masks=None):
+                calls.append({"x": conditions["x"].clone(), "masks": conditions["masks"].clone(), "returns": returns.clone(),
+                              "env_ts": env_ts.clone(), "attention_masks": attention_masks.clone()})
+                return torch.from_numpy(np.asarray(O.closed_form_normal(f"g10.{tag}.plan", tuple(conditions["x"].shape)),
+                                                   dtype=np.float32))
+
+        cfg = types.SimpleNamespace(max_path_length=25, horizon=horizon, history_horizon=hh, n_agents=A,
+                                    decentralized_execution=dec, device="cpu")
+        fake = types.SimpleNamespace(Config=cfg, trainer=types.SimpleNamespace(ema_model=FakeEMA()),
+                                     mask_generator=mg.MultiAgentMaskGenerator(action_dim=2, observation_dim=F,
+                                                                               history_horizon=hh, action_visible=False))
+        obs = np.asarray(O.closed_form_normal(f"g10.{tag}.obs", (B, hh + 1, A, F)), dtype=np.float32)
+        returns = 0.9 * torch.ones(B, 1, A)
+        env_ts = (torch.arange(horizon + hh) - hh)[None].repeat(B, 1) + torch.tensor([0, 21, 3][:B])[:, None]
+        samples = ev.MADEvaluatorWorker._generate_samples(fake, obs, returns, env_ts)
+        assert len(calls) == 1
+        c = calls[0]
+        out.update({f"{tag}.obs": obs, f"{tag}.returns": returns.numpy(), f"{tag}.env_ts": env_ts.numpy(),
+                    f"{tag}.cond_x": c["x"].numpy(), f"{tag}.cond_masks": c["masks"].numpy().astype(np.uint8),
+                    f"{tag}.call_returns": c["returns"].numpy(), f"{tag}.call_env_ts": c["env_ts"].numpy(),
+                    f"{tag}.samples": samples.numpy(), f"{tag}.geom": np.asarray([A, horizon, hh, F, B, int(dec)])})
+    save("g10_planner", **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "planner":
+        gen_planner()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "alternates":
         torch.manual_seed(1234)
         torch.set_num_threads(8)

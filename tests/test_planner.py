@@ -27,6 +27,34 @@ class _Shape:
         self.n_agents, self.horizon, self.history_horizon, self.observation_dim = A, h, hh, F
 
 
+@pytest.mark.parametrize("tag", ["cen", "dec", "dec_nohist"])
+def test_planner_calls_sampler_like_reference_evaluator(golden, tag):
+    """tests/golden/g10_planner.npz was recorded from the reference's own MADEvaluatorWorker._generate_samples
+    (evaluator.py:39-135) driving a recording stand-in sampler: the conditioning trajectories / masks it builds, the
+    returns / env_ts it passes (clamp at max_path_length, (b a) expansion) and the plans it hands back (decentralized
+    gather, history cut) -- DevicePlanner must call its sampler with the same tensors and return the same plans, both
+    paths fed with and returning the same closed-form stand-in plan."""
+    from madiff_amd.planner import DevicePlanner
+    g = golden("g10_planner")
+    A, h, hh, F, B, dec = (int(v) for v in g[f"{tag}.geom"])
+    calls = []
+
+    class Recording(_Shape):
+        def conditional_sample(self, cond, returns=None, env_ts=None, verbose=False, **kw):
+            calls.append((cond["x"].clone(), cond["masks"].clone(), returns.clone(), env_ts.clone()))
+            return torch.from_numpy(np.asarray(O.closed_form_normal(f"g10.{tag}.plan", tuple(cond["x"].shape)), dtype=np.float32))
+
+    pl = DevicePlanner(Recording(A, h, hh, F), bool(dec), max_path_length=25)
+    out = pl.generate_samples(torch.from_numpy(g[f"{tag}.obs"]), torch.from_numpy(g[f"{tag}.returns"]),
+                              torch.from_numpy(g[f"{tag}.env_ts"]))
+    cx, cm, r, ets = calls[0]
+    assert np.array_equal(cx.numpy(), g[f"{tag}.cond_x"])
+    assert np.array_equal(cm.numpy().astype(np.uint8), g[f"{tag}.cond_masks"])
+    assert np.array_equal(r.numpy(), g[f"{tag}.call_returns"])
+    assert np.array_equal(ets.numpy(), g[f"{tag}.call_env_ts"])
+    assert np.array_equal(out.numpy(), g[f"{tag}.samples"])
+
+
 @pytest.mark.parametrize("decentralized", [False, True])
 @pytest.mark.parametrize("hh", [0, 5])
 def test_planner_conditions_match_oracle(decentralized, hh):
