@@ -151,6 +151,13 @@ int madiff_attn_fwd(int dtype, const void* qkv, int ldq, const void* x, int ldx,
 int madiff_attn_bwd(int dtype, const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg, const float* gamma,
                     float* dgamma, int B, int A, int T, int H, int Cq, int C, int residual, madiff_stream_t stream);
 
+/* madiff_attn_bwd that also yields the gradient of the per-sequence row bias of the fused [q | k | v] projection, i.e. of
+   the three timestep MLP outputs TemporalSelfAttention adds to q, k, v (reference diffuser/models/temporal.py:100-111):
+   drowbias[(b,a), col] = sum_t dqkv[(b,a,t), col], fp32 [B*A, ldrb], columns [0, 2Cq + C).  drowbias = NULL: madiff_attn_bwd. */
+int madiff_attn_bwd_rb(int dtype, const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg,
+                       const float* gamma, float* dgamma, float* drowbias, int ldrb, int B, int A, int T, int H, int Cq,
+                       int C, int residual, madiff_stream_t stream);
+
 /* [B,T,A,F] fp32 -> [(b a), t, Fpad] storage type, optionally fused with add_noise (diffusers DDPMScheduler.add_noise,
  * called at models/diffusion.py:292) and inpainting (helpers.py:194-196, diffusion.py:293).  x_noisy (fp32, may be null)
  * receives the noised + inpainted trajectory in the reference layout.  x_ld: feature-row stride of x in elements (x may

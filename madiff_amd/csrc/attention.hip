@@ -133,7 +133,8 @@ extern "C" int madiff_attn_fwd_v2(int dtype, const void* qkv, int ldq, const voi
                                   int B, int A, int T, int H, int Cq, int C, float scale, int residual, hipStream_t stream);
 extern "C" int madiff_attn_bwd_v2(int dtype, const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg,
                                   const float* gamma, float* dgamma, int B, int A, int T, int H, int Cq, int C, float scale,
-                                  int residual, hipStream_t stream);
+                                  int residual, float* drb, int ldrb, hipStream_t stream);
+extern "C" int madiff_seqsum(int dtype, const void* x, int ld, float* out, int ldo, long N, int T, int C, hipStream_t stream);
 
 static int att_check(int B, int A, int T, int H, int Cq, int C) {
   return (B > 0 && A > 0 && T > 0 && H > 0 && Cq > 0 && C > 0 && Cq % H == 0 && C % H == 0 &&
@@ -160,16 +161,37 @@ extern "C" int madiff_attn_fwd(int dtype, const void* qkv, int ldq, const void* 
   return 0;
 }
 
+extern "C" int madiff_attn_bwd_rb(int dtype, const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg,
+                                  const float* gamma, float* dgamma, float* drowbias, int ldrb, int B, int A, int T, int H,
+                                  int Cq, int C, int residual, hipStream_t stream);
+
 // dgamma (1 float) must be zeroed by the caller; dqkv gets every column of the fused [q | k | v] gradient.
 extern "C" int madiff_attn_bwd(int dtype, const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg,
                                const float* gamma, float* dgamma, int B, int A, int T, int H, int Cq, int C,
                                int residual, hipStream_t stream) {
-  if (att_check(B, A, T, H, Cq, C) || ldq < 2 * Cq + C || ldd < C || ldg < 2 * Cq + C || (residual && (!gamma || !dgamma)))
+  return madiff_attn_bwd_rb(dtype, qkv, ldq, dout, ldd, dqkv, ldg, gamma, dgamma, nullptr, 0, B, A, T, H, Cq, C, residual, stream);
+}
+
+// madiff_attn_bwd that also returns the gradient of the per-sequence row bias added to the fused [q | k | v] projection
+// (the timestep conditioning, temporal.py:100-111): drowbias[(b,a), col] = sum_t dqkv[(b,a,t), col], fp32 [B*A, ldrb],
+// every column in [0, 2Cq + C) written.  NULL = not wanted.
+extern "C" int madiff_attn_bwd_rb(int dtype, const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg,
+                                  const float* gamma, float* dgamma, float* drowbias, int ldrb, int B, int A, int T, int H,
+                                  int Cq, int C, int residual, hipStream_t stream) {
+  if (att_check(B, A, T, H, Cq, C) || ldq < 2 * Cq + C || ldd < C || ldg < 2 * Cq + C || (residual && (!gamma || !dgamma)) ||
+      (drowbias && ldrb < 2 * Cq + C))
     return -1;
   float scale = 1.0f / sqrtf((float)(Cq / H) * (float)T);
   {
-    int rc = madiff_attn_bwd_v2(dtype, qkv, ldq, dout, ldd, dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual, stream);
+    int rc = madiff_attn_bwd_v2(dtype, qkv, ldq, dout, ldd, dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual,
+                                drowbias, ldrb, stream);
     if (rc <= 0) return rc;
+    if (drowbias) {      // no room for the sums next to the staged q / k slices: the same kernel without them, then the sums
+      rc = madiff_attn_bwd_v2(dtype, qkv, ldq, dout, ldd, dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual, nullptr,
+                              0, stream);
+      if (rc < 0) return rc;
+      if (rc == 0) return madiff_seqsum(dtype, dqkv, ldg, drowbias, ldrb, (long)B * A, T, 2 * Cq + C, stream);
+    }
   }
   int blocks = B < 4096 ? B : 4096;
   if (dtype == MADIFF_BF16)
@@ -179,6 +201,7 @@ extern "C" int madiff_attn_bwd(int dtype, const void* qkv, int ldq, const void* 
     hipLaunchKernelGGL((attn_bwd_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)qkv, ldq,
                        (const float*)dout, ldd, (float*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual);
   MADIFF_CHECK_LAUNCH();
+  if (drowbias) return madiff_seqsum(dtype, dqkv, ldg, drowbias, ldrb, (long)B * A, T, 2 * Cq + C, stream);
   return 0;
 }
 
@@ -303,7 +326,7 @@ template <typename T, int AM>
 __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(const T* __restrict__ qkv, int ldq, const T* __restrict__ dout, int ldd,
                                                           T* __restrict__ dqkv, int ldg, const float* __restrict__ gamma_p,
                                                           float* __restrict__ dgamma, int B, int A, int Tn, int H, int Cq, int C,
-                                                          float scale, int residual) {
+                                                          float scale, int residual, float* __restrict__ drb, int ldrb) {
   constexpr int E = AVec<T>::E;
   extern __shared__ float sm[];
   __shared__ float Dw[4][AM * AM];
@@ -313,6 +336,12 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(const T* __restrict__ 
   float* ks = sm + A * L;
   float* Ps = ks + A * L;
   float* Ds = Ps + A * A;
+  // drb != null: also the gradient of the per-sequence row bias of the fused projection (the time-MLP outputs added to
+  // q, k, v: temporal.py:100-111), d bias[(b,a), col] = sum_t dqkv[(b,a,t), col] -- this workgroup owns head h's columns
+  // of its A rows, so the sums are built in LDS ([A][q | k | v of the head]) and stored without atomics in global memory.
+  // The sums never touch dqkv again: sum_t dq[a] = sum_o dS[a][o] (sum_t k[o]) and likewise for dk, from the slices already
+  // in LDS; sum_t dv[a2] = gamma * sum_a1 P[a1][a2] (sum_t dO[a1]) from a second (cache-hot) read of dO.
+  float* Rs = Ds + A * A;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const float gamma = residual ? gamma_p[0] : 1.f;
   att2_scores<T>(qkv, ldq, b, h, A, Tn, dqk, Cq, scale, qs, ks, Ps);
@@ -405,9 +434,40 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(const T* __restrict__ 
     ast<T>(dst, oq);
     ast<T>(dst + Cq, ok);
   }
+  if (drb) {
+    for (int i = threadIdx.x; i < A * dqk; i += 256) {
+      const int a = i / dqk, c = i - a * dqk;
+      float sq = 0.f, sk = 0.f;
+      for (int o = 0; o < A; o++) {
+        float ksum = 0.f, qsum = 0.f;
+        for (int t = 0; t < Tn; t++) { ksum += ks[o * L + t * dqk + c]; qsum += qs[o * L + t * dqk + c]; }
+        sq += Ds[a * A + o] * ksum;
+        sk += Ds[o * A + a] * qsum;
+      }
+      float* dst = drb + (size_t)(b * A + a) * ldrb + h * dqk + c;
+      dst[0] = sq;
+      dst[Cq] = sk;
+    }
+    for (int i = threadIdx.x; i < A * dv; i += 256) {
+      const int a1 = i / dv, c = i - a1 * dv;
+      const T* src = dout + (size_t)(b * A + a1) * Tn * ldd + h * dv + c;
+      float g = 0.f;
+      for (int t = 0; t < Tn; t++) g += (float)src[(size_t)t * ldd];
+      Rs[i] = g;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A * dv; i += 256) {
+      const int a2 = i / dv, c = i - a2 * dv;
+      float v = 0.f;
+      for (int a1 = 0; a1 < A; a1++) v += Ps[a1 * A + a2] * Rs[a1 * dv + c];
+      drb[(size_t)(b * A + a2) * ldrb + 2 * Cq + h * dv + c] = gamma * v;
+    }
+  }
 }
 
-static size_t att2_lds(int A, int T, int H, int Cq) { return ((size_t)2 * A * T * (Cq / H) + 2 * A * A) * sizeof(float); }
+static size_t att2_lds(int A, int T, int H, int Cq, int C = 0) {   // C > 0: + the row-bias gradient sums of the backward kernel
+  return ((size_t)2 * A * T * (Cq / H) + 2 * A * A + (C > 0 ? (size_t)A * (C / H) : 0)) * sizeof(float);
+}
 
 static int att2_ok(int dtype, int A, int T, int H, int Cq, int C, int ld1, int ld2, int ld3) {
   const int E = dtype == MADIFF_BF16 ? 8 : 4;
@@ -430,12 +490,13 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_attn_fwd_v2(int dtyp
 
 extern "C" __attribute__((visibility("hidden"))) int madiff_attn_bwd_v2(int dtype, const void* qkv, int ldq, const void* dout, int ldd,
     void* dqkv, int ldg, const float* gamma, float* dgamma, int B, int A, int T, int H, int Cq, int C, float scale, int residual,
-    hipStream_t stream) {
+    float* drb, int ldrb, hipStream_t stream) {
   if (!att2_ok(dtype, A, T, H, Cq, C, ldq, ldd, ldg)) return 1;
-  size_t sh = att2_lds(A, T, H, Cq);
+  size_t sh = att2_lds(A, T, H, Cq, drb ? C : 0);
+  if (sh > 60 * 1024) return 1;
 #define ATT2_BWD(T_, AM_)                                                                                                  \
   hipLaunchKernelGGL((attn_bwd_v2_kernel<T_, AM_>), dim3(B * H), dim3(256), sh, stream, (const T_*)qkv, ldq, (const T_*)dout, \
-                     ldd, (T_*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual)
+                     ldd, (T_*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual, drb, ldrb)
   if (dtype == MADIFF_BF16) { if (A <= 4) ATT2_BWD(bf16_t, 4); else ATT2_BWD(bf16_t, 8); }
   else { if (A <= 4) ATT2_BWD(float, 4); else ATT2_BWD(float, 8); }
 #undef ATT2_BWD

@@ -43,6 +43,7 @@ _SIGS = {
     "madiff_gn_mish_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_attn_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_attn_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "madiff_attn_bwd_rb": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_pack_input": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_loss_ws_doubles": [],
     "madiff_loss_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],

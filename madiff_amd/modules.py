@@ -20,7 +20,7 @@ import torch.nn as nn
 from torch.distributions import Bernoulli
 
 from . import ops
-from .ops import CONV1, CONV5, DOWN, LINEAR, UP, AttnCore, GNMish, PackTraj, conv_gemm, mish, pad32
+from .ops import CONV1, CONV5, DOWN, LINEAR, UP, AttnBlock, AttnCore, GNMish, PackTraj, conv_gemm, mish, pad32
 
 
 # ------------------------------------------------------------------------------------------------
@@ -141,6 +141,7 @@ class Conv1dBlock(nn.Module):
 # temporal.py
 # ------------------------------------------------------------------------------------------------
 RES_BLOCK_NODE = os.environ.get("MADIFF_RES_BLOCK", "1") != "0"
+ATTN_BLOCK_NODE = os.environ.get("MADIFF_ATTN_BLOCK", "1") != "0"
 
 
 class ResidualTemporalBlock(nn.Module):
@@ -204,6 +205,10 @@ class TemporalSelfAttention(nn.Module):
 
     def forward_cl(self, x, bsz, n_agents, t, time_proj):
         """x cl [(b a) t, C]; time_proj fp32 [B*A, >= 2cq + C] = [q | k | v] time-MLP outputs."""
+        if ATTN_BLOCK_NODE:          # projection + attention core as one autograd node (ops.AttnBlock)
+            return AttnBlock.apply(x, time_proj, self.gamma if self.residual else None, bsz, n_agents, t, self.nheads,
+                                   self.cq, self.n_channels, self.residual, self.query_layer.weight, self.key_layer.weight,
+                                   self.value_layer.weight, self.query_layer.bias, self.key_layer.bias, self.value_layer.bias)
         qkv = conv_gemm(x, [self.query_layer.weight, self.key_layer.weight, self.value_layer.weight],
                         [self.query_layer.bias, self.key_layer.bias, self.value_layer.bias], CONV1, t,
                         rowbias=time_proj)
@@ -241,6 +246,10 @@ class SelfAttention(nn.Module):
             raise NotImplementedError("value width must equal the channel count (out.reshape(x.shape), helpers.py:121)")
 
     def forward_cl(self, x, bsz, n_agents, t):
+        if ATTN_BLOCK_NODE:
+            return AttnBlock.apply(x, None, self.gamma if self.residual else None, bsz, n_agents, t, self.nheads,
+                                   self.cq, self.n_channels, self.residual, self.query_layer.weight, self.key_layer.weight,
+                                   self.value_layer.weight, self.query_layer.bias, self.key_layer.bias, self.value_layer.bias)
         qkv = conv_gemm(x, [self.query_layer.weight, self.key_layer.weight, self.value_layer.weight],
                         [self.query_layer.bias, self.key_layer.bias, self.value_layer.bias], CONV1, t)
         return AttnCore.apply(qkv, x, self.gamma if self.residual else None, bsz, n_agents, t, self.nheads, self.cq,

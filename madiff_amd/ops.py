@@ -1299,6 +1299,60 @@ class AttnCore(torch.autograd.Function):
         return dqkv, (dout if residual else None), dgamma, None, None, None, None, None, None, None
 
 
+class AttnBlock(torch.autograd.Function):
+    """TemporalSelfAttention / SelfAttention (temporal.py:57-124, helpers.py:77-124) as ONE autograd node: the fused
+    Q/K/V projection (+ per-sequence time bias) and the attention core.  Backward then (a) takes the time-bias gradient
+    from the attention-backward kernel itself (madiff_attn_bwd_rb: no pass over dqkv to sum over t), and (b) hands the
+    residual path's gradient (out = x + gamma * attn: dx gets dout) to the projection's data-gradient kernel as an
+    epilogue addend instead of a separate add.
+
+    apply(x, time_proj | None, gamma | None, B, A, T, H, Cq, C, residual, wq, wk, wv, bq, bk, bv)"""
+
+    @staticmethod
+    def forward(ctx, x, time_proj, gamma, B, A, T, H, Cq, C, residual: bool, wq, wk, wv, bq, bk, bv):
+        weights, biases = [wq, wk, wv], [bq, bk, bv]
+        qkv, g = _conv_forward(x, None, time_proj, CONV1, T, 0, None, weights, biases)
+        _chk_cl(qkv)
+        out = torch.empty_like(x)
+        if out.shape[1] > C:
+            out[:, C:].zero_()
+        _timed("attn_fwd_v2_kernel", 0.0, lambda: lib.call(
+            "madiff_attn_fwd", _dt(), qkv.data_ptr(), qkv.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
+            out.stride(0), _p(gamma), B, A, T, H, Cq, C, int(residual), _stream()),
+            nbytes=float(B * A * T * (2 * Cq + 3 * C) * x.element_size()))
+        ctx.save_for_backward(x, qkv, gamma, *weights, *biases)
+        ctx.g, ctx.geom, ctx.has_rb = g, (B, A, T, H, Cq, C, residual), time_proj is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, qkv, gamma = ctx.saved_tensors[:3]
+        weights, biases = list(ctx.saved_tensors[3:6]), list(ctx.saved_tensors[6:9])
+        B, A, T, H, Cq, C, residual = ctx.geom
+        needs = ctx.needs_input_grad
+        dout = dout.contiguous()
+        if dout.dtype != act_dtype():
+            dout = dout.to(act_dtype())
+        dqkv = torch.empty_like(qkv)
+        ncol = 2 * Cq + C
+        if dqkv.shape[1] > ncol:
+            dqkv[:, ncol:].zero_()
+        view = _sink_view(gamma) if residual else None
+        dgamma = view if view is not None else (torch.zeros(1, dtype=torch.float32, device=qkv.device) if residual else None)
+        drb = torch.empty(B * A, ncol, dtype=torch.float32, device=qkv.device) if (ctx.has_rb and needs[1]) else None
+        _timed("attn_bwd_v2_kernel", 0.0, lambda: lib.call(
+            "madiff_attn_bwd_rb", _dt(), qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0), dqkv.data_ptr(),
+            dqkv.stride(0), _p(gamma), _p(dgamma), _p(drb), 0 if drb is None else drb.stride(0), B, A, T, H, Cq, C,
+            int(residual), _stream()), nbytes=float(B * A * T * (2 * ncol + C) * qkv.element_size()))
+        if view is not None:
+            SINK.done(gamma)
+            dgamma = None
+        dx, _, _, gw, gb = _conv_backward(ctx.g, x, None, weights, biases, dqkv, needs[0], False,
+                                          [needs[10], needs[11], needs[12]], "colsum", False,
+                                          addends=(dout if residual else None, None))
+        return (dx, drb, dgamma, None, None, None, None, None, None, None, *gw, *gb)
+
+
 class Act(torch.autograd.Function):
     """Mish (kind 2) / ReLU (kind 1) on a cl tensor (pad columns stay zero: both map 0 -> 0)."""
 
