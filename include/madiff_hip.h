@@ -100,6 +100,17 @@ int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred, int taps,
                              int tr, const void* W, int ldw, int wtap, int wcol0, int Ncols, int Npad, void* dX, int ldx,
                              int tile, int ksplit, const void* addend, int ld_add, madiff_stream_t stream);
 
+/* Backward of "Conv1dBlock A, then a k5 convolution B" in one launch (bf16 build): B's data gradient (dh = dY (*) W_B from
+   B's forward weight matrix, as madiff_gemm_dgrad_wt) with block A's GroupNorm + Mish backward as the kernel's epilogue
+   (reference diffuser/models/helpers.py:63-71 differentiated; in ResidualTemporalBlock, temporal.py:197-200: A = blocks[0],
+   B = blocks[1]'s Conv1d).  Ypre / mean / rstd: what A's forward saved.  dX <- gradient of A's pre-norm conv output; dgamma,
+   dbeta, dbias (A's conv bias, may be NULL) accumulated atomically; drowbias [M/T, ldrb] = sum_t dh (gradient of the
+   per-sequence time-embedding term) may be NULL.  variant 1 | 2 = 96- | 192-row tile.  Returns 1 when not covered. */
+int madiff_conv_dgrad_gn_bwd(const void* dY, int ldy, int M, int Kred, int T, const void* W, int ldw, int wtap, int Ncols,
+                             const void* Ypre, int ldyp, const float* gamma, const float* beta, const float* mean,
+                             const float* rstd, int G, void* dX, int ldx, float* dgamma, float* dbeta, float* dbias,
+                             float* drowbias, int ldrb, int variant, madiff_stream_t stream);
+
 /* Weight gradient of the above: dW[o, tap*Cin + c] (+)= sum_m dY[m, o] * X[src(m, tap), c]  (fp32 output).
  * Replaces the wgrad half of autograd for the same modules.  accumulate != 0 adds into dW (a live gradient buffer
  * kept in this GEMM layout by the flat optimizer), 0 overwrites.  tile: variant of the gfx950 LDS-DMA kernel, < 0 =

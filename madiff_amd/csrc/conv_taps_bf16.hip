@@ -56,14 +56,22 @@ struct GnEpi {
   const bf16_t* res; int ldr;
   int G, gv_log2;                             // groups; log2(16-byte... 8-channel vectors per group)
   float eps;
+  // GroupNorm BACKWARD fused into the data-gradient kernel (GNB): the tile of dh = dgrad(conv) holds whole sequences x
+  // whole groups of the PRECEDING Conv1dBlock's output, so that block's GroupNorm + Mish backward runs here and the kernel
+  // stores dy (gradient of the preceding conv's pre-norm output) instead of dh.
+  const bf16_t* by; int ldby;                 // pre-norm output y of the preceding block (saved by its forward)
+  const float* bmean; const float* brstd;     // its statistics [n_seq * G]
+  float* dgamma; float* dbeta; float* dbias;  // [C], accumulated atomically (dbias = the preceding conv's bias gradient, may be null)
+  float* drowb; int lddrb;                    // d rowbias [n_seq, lddrb] = sum_t dh (mode 1: the time-embedding term), or null
 };
 
 // D = 3 / 4: one barrier per (chunk, tap) step.  D = 5: one barrier per TWO steps (the ring then holds the three stages a
 // double-step reads or prefetches from plus the two in flight; needs an even number of channel chunks).
-template <int WM, bool WT, int D, bool GN, int VPL = 0>
+template <int WM, bool WT, int D, bool GN, int VPL = 0, bool GNB = false>
 __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams p, int rows_used, int shift0, int shift_step,
                                                                   GnEpi ge) {
   static_assert(!(GN && WT), "the GroupNorm epilogue belongs to the forward kernel");
+  static_assert(!GNB || (WT && !GN), "the GroupNorm-backward epilogue belongs to the data-gradient kernel");
   constexpr int TAPS = 5;
   static_assert(D == 3 || D == 4 || D == 5, "W ring depth");
   constexpr int BM = 48 * WM, NW = 2 * WM, NT = NW * 64;
@@ -441,6 +449,141 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
     return;
   }
 
+  if constexpr (GNB) {
+    // ---- fused GroupNorm + Mish BACKWARD of the preceding Conv1dBlock (helpers.py:63-71 differentiated; the arithmetic of
+    // gn_mish_bwd_rb_kernel).  Same geometry as the forward epilogue: (0) y vectors and statistics of the wave's sequences
+    // are requested first; (1) accumulators (= dh) -> fp32 LDS image of the tile; (2) lane = (row r0, 8-channel vector cv),
+    // per sequence: x^ = (y - mean) rstd, dz = dh mish'(x^ g + b), group sums s1 = mean(dz g), s2 = mean(dz g x^) by
+    // butterflies, dy = rstd (dz g - s1 - x^ s2); (3) per-channel sums (dgamma, dbeta, dbias) stay in registers over the
+    // wave's sequences, then lanes -> waves (LDS) -> one atomic per channel per workgroup; d rowbias = sum_t dh per sequence.
+    constexpr int LDG = 132;
+    constexpr int SEQ = 8 / VPL;
+    static_assert(VPL >= 1 && SEQ >= 1, "VPL in 1..8");
+    static_assert(BM * LDG * 4 <= 2 * A_BYTES + D * W_BYTES, "tile image must fit the operand LDS");
+    float* tile = (float*)smem;
+    const int cv = lane & 15, r0 = lane >> 4, c0 = n0 + cv * 8;
+    const int Cg = p.Nout / ge.G;
+    const float inv_e = 1.f / (float)(T * Cg);
+    const int spt = rows_used / T, n_seq = p.M / T;
+    const int g = c0 / Cg;
+    bf16x8 yv[SEQ][VPL];
+    float mean[SEQ], rstd[SEQ];
+    float gmv[8], btv[8], a_dg[8], a_db[8], a_dbias[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { gmv[e] = ge.gamma[c0 + e]; btv[e] = ge.beta[c0 + e]; a_dg[e] = a_db[e] = a_dbias[e] = 0.f; }
+#pragma unroll
+    for (int sl = 0; sl < SEQ; sl++) {
+      const int sq = wave + sl * NW, n = bx * spt + sq;
+      const bool live = sq < spt && n < n_seq;
+      mean[sl] = live ? ge.bmean[(size_t)n * ge.G + g] : 0.f;
+      rstd[sl] = live ? ge.brstd[(size_t)n * ge.G + g] : 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        const int r = r0 + 4 * i;
+        if (live && r < T) yv[sl][i] = *(const bf16x8*)(ge.by + ((size_t)n * T + r) * ge.ldby + c0);
+      }
+    }
+    __syncthreads();                         // every wave is done with the operand tiles; no DMA is outstanding
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int col = wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) tile[(wm * 48 + i * 16 + fq * 4 + r) * LDG + col] = acc[i][j][r];
+    }
+    __syncthreads();
+    bf16_t* DY = (bf16_t*)p.C;
+#pragma unroll
+    for (int sl = 0; sl < SEQ; sl++) {
+      const int sq = wave + sl * NW, n = bx * spt + sq;
+      const bool live = sq < spt && n < n_seq;
+      float dxh[VPL][8], rbs[8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) rbs[e] = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        const int r = r0 + 4 * i;
+        if (live && r < T) {
+          const f32x4 a = *(const f32x4*)&tile[(sq * T + r) * LDG + cv * 8];
+          const f32x4 b = *(const f32x4*)&tile[(sq * T + r) * LDG + cv * 8 + 4];
+          const float go[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float x = ((float)yv[sl][i][e] - mean[sl]) * rstd[sl];
+            const float dz = go[e] * mish_grad_f(__builtin_fmaf(x, gmv[e], btv[e]));
+            a_dg[e] = __builtin_fmaf(dz, x, a_dg[e]);
+            a_db[e] += dz;
+            rbs[e] += go[e];
+            const float d = dz * gmv[e];
+            dxh[i][e] = d;
+            s1 += d;
+            s2 = __builtin_fmaf(d, x, s2);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; e++) dxh[i][e] = 0.f;
+        }
+      }
+      // lanes of one group differ in bits [0, gv_log2) (vector inside the group) and bits 4, 5 (row)
+      for (int b = 0; b < ge.gv_log2; b++) { s1 += __shfl_xor(s1, 1 << b, 64); s2 += __shfl_xor(s2, 1 << b, 64); }
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      s1 *= inv_e; s2 *= inv_e;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        const int r = r0 + 4 * i;
+        if (live && r < T) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float x = ((float)yv[sl][i][e] - mean[sl]) * rstd[sl];
+            const float v = rstd[sl] * (dxh[i][e] - s1 - x * s2);
+            a_dbias[e] += v;
+            o[e] = (bf16_t)v;
+          }
+          *(bf16x8*)(DY + ((size_t)n * T + r) * p.ldc + c0) = o;
+        }
+      }
+      if (ge.drowb) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { rbs[e] += __shfl_xor(rbs[e], 16, 64); rbs[e] += __shfl_xor(rbs[e], 32, 64); }
+        if (live && r0 == 0) {
+          float* dst = ge.drowb + (size_t)n * ge.lddrb + c0;
+          *(f32x4*)dst = (f32x4){rbs[0], rbs[1], rbs[2], rbs[3]};
+          *(f32x4*)(dst + 4) = (f32x4){rbs[4], rbs[5], rbs[6], rbs[7]};
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      a_dg[e] += __shfl_xor(a_dg[e], 16, 64); a_dg[e] += __shfl_xor(a_dg[e], 32, 64);
+      a_db[e] += __shfl_xor(a_db[e], 16, 64); a_db[e] += __shfl_xor(a_db[e], 32, 64);
+      a_dbias[e] += __shfl_xor(a_dbias[e], 16, 64); a_dbias[e] += __shfl_xor(a_dbias[e], 32, 64);
+    }
+    __syncthreads();                         // the tile image has been read by every wave: its LDS is free
+    float* red = (float*)smem;               // [wave][dgamma | dbeta | dbias][128 channels]
+    if (r0 == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        red[(wave * 3 + 0) * 128 + cv * 8 + e] = a_dg[e];
+        red[(wave * 3 + 1) * 128 + cv * 8 + e] = a_db[e];
+        red[(wave * 3 + 2) * 128 + cv * 8 + e] = a_dbias[e];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * 128; i += NT) {
+      const int q = i >> 7, c = i & 127;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) a += red[(w * 3 + q) * 128 + c];
+      float* dst = q == 0 ? ge.dgamma : (q == 1 ? ge.dbeta : ge.dbias);
+      if (dst) atomicAdd(&dst[n0 + c], a);
+    }
+    return;
+  }
+
   // ---- epilogue (vector path only; the launcher checks the alignment preconditions)
   bf16_t* C = (bf16_t*)p.C;
   constexpr int WN = 64, LDT = WN + 4, VPR = WN / 8, RPP = 64 / VPR;
@@ -599,6 +742,62 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_
   else return 1;               // (the 4-deep-ring form of the 192-row tile has no fused epilogue: use variant 2)
 #undef CT_GN_VPL
 #undef CT_GN
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Data gradient of a k5 "same" convolution + the GroupNorm/Mish backward of the Conv1dBlock that produced its input, in one
+// launch (conv_taps WT kernel with the GNB epilogue).  p: the data-gradient problem as madiff_gemm_dgrad_wt builds it
+// (p.C / p.ldc receive dy of the preceding block instead of dh).  Returns 1 when the layer is not covered.
+extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gnb_bf16(
+    const void* params, int variant, const void* ypre, int ldyp, const float* gamma, const float* beta, const float* mean,
+    const float* rstd, int G, float* dgamma, float* dbeta, float* dbias, float* drowbias, int ldrb, hipStream_t stream) {
+  GemmFwdParams p = *(const GemmFwdParams*)params;
+  const int BM = variant == 1 ? 96 : 192;
+  const int T = p.rm.T_out;
+  if (variant == 2 && p.Cin % 128) return 1;
+  if (!p.wt || p.taps != 5 || p.rm.stride != 1 || p.rm.tr != 1 || p.rm.pad != 2 || p.rm.T_in != T || T > 32 || p.permA > 0 ||
+      p.ksplit > 1 || p.Cin % 64 || p.M % T || p.act != 0 || p.rowbias || p.bias || p.addend || p.X2)
+    return 1;
+  if (G <= 0 || p.Nout % 128 || p.Npad != p.Nout || p.Nout % G || p.wcols < p.Nout) return 1;
+  const int Cg = p.Nout / G;
+  if (Cg % 8 || 128 % Cg) return 1;
+  int gl = 0;
+  while ((8 << gl) < Cg) gl++;
+  if ((8 << gl) != Cg) return 1;
+  if (!ypre || !gamma || !beta || !mean || !rstd || !dgamma || !dbeta || !p.C || ldyp < p.Nout || p.ldc < p.Nout ||
+      (drowbias && ldrb < p.Nout))
+    return -1;
+  if (((size_t)ypre % 16) || (ldyp % 8) || ((size_t)p.C % 16) || (p.ldc % 8) || (drowbias && (((size_t)drowbias % 16) || ldrb % 4)))
+    return 1;
+  {
+    const size_t wext = (size_t)p.Cin * p.ldw * 2;
+    if ((size_t)p.M * (size_t)p.ldx * 2 >= (1ull << 31) || wext >= (1ull << 31)) return 1;
+  }
+  GnEpi ge = {};
+  ge.gamma = gamma; ge.beta = beta; ge.G = G; ge.gv_log2 = gl;
+  ge.by = (const bf16_t*)ypre; ge.ldby = ldyp; ge.bmean = mean; ge.brstd = rstd;
+  ge.dgamma = dgamma; ge.dbeta = dbeta; ge.dbias = dbias; ge.drowb = drowbias; ge.lddrb = ldrb;
+  const int spt = BM / T, rows_used = spt * T;
+  const int n_seq = p.M / T;
+  dim3 grid((n_seq + spt - 1) / spt, p.Nout / 128);
+  const int vpl = (T + 3) / 4, nw = variant == 1 ? 4 : 8;
+  if ((spt + nw - 1) / nw > 8 / vpl) return 1;
+#define CT_GNB(WM_, D_, V_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, true, D_, false, V_, true>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, 2, -1, ge)
+#define CT_GNB_VPL(WM_, D_)                                   \
+  switch (vpl) {                                              \
+    case 2: CT_GNB(WM_, D_, 2); break;                        \
+    case 3: CT_GNB(WM_, D_, 3); break;                        \
+    case 4: CT_GNB(WM_, D_, 4); break;                        \
+    case 6: CT_GNB(WM_, D_, 6); break;                        \
+    case 7: CT_GNB(WM_, D_, 7); break;                        \
+    default: return 1;                                        \
+  }
+  if (variant == 2) { CT_GNB_VPL(4, 5) }
+  else if (variant == 1) { CT_GNB_VPL(2, 3) }
+  else return 1;
+#undef CT_GNB_VPL
+#undef CT_GNB
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

@@ -521,6 +521,39 @@ extern "C" int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred
 
 extern "C" int madiff_colsum(int dtype, const void* x, int ld, float* out, long M, int C, hipStream_t stream);
 extern "C" int madiff_colsum_scatter(int dtype, const void* x, int ld, float* const* table, long M, int C, hipStream_t stream);
+extern "C" int madiff_launch_conv_taps_gnb_bf16(const void* params, int variant, const void* ypre, int ldyp, const float* gamma,
+                                                const float* beta, const float* mean, const float* rstd, int G, float* dgamma,
+                                                float* dbeta, float* dbias, float* drowbias, int ldrb, hipStream_t stream);
+
+// Backward of "Conv1dBlock A -> k5 convolution B" in ONE launch (bf16 build): the data gradient of B (as
+// madiff_gemm_dgrad_wt: dh = dY (*) W_B, straight from B's forward weight matrix) followed, in the kernel's epilogue, by the
+// GroupNorm(G) + Mish backward of block A (helpers.py:63-71 differentiated; what madiff_gn_mish_bwd computes), whose
+// pre-norm output Ypre and statistics its forward saved.  dX receives dy_A (gradient of A's pre-norm conv output), dh is
+// never stored.  dgamma / dbeta / dbias ([C], dbias = gradient of A's conv bias, may be NULL) are accumulated atomically;
+// drowbias ([M/T, ldrb] = sum_t dh, the gradient of the per-sequence term added after A: temporal.py:197) may be NULL.
+// In ResidualTemporalBlock: A = blocks[0], B = blocks[1]'s convolution.  variant: 1 = 96-row tile, 2 = 192-row tile.
+// Returns 1 when the layer is not covered (caller: madiff_gemm_dgrad_wt + madiff_gn_mish_bwd).
+extern "C" int madiff_conv_dgrad_gn_bwd(const void* dY, int ldy, int M, int Kred, int T, const void* W, int ldw, int wtap,
+                                        int Ncols, const void* Ypre, int ldyp, const float* gamma, const float* beta,
+                                        const float* mean, const float* rstd, int G, void* dX, int ldx, float* dgamma,
+                                        float* dbeta, float* dbias, float* drowbias, int ldrb, int variant,
+                                        hipStream_t stream) {
+  if (M <= 0 || Ncols <= 0) return 0;
+  if (!use_dma_kernel() || Kred % 64 || wtap % 8 || ldw % 8) return 1;
+  if (T <= 0 || M % T || ldy < Kred || ldy % 8 || ldx < Ncols || Ncols > wtap || ldw < 5 * wtap || variant < 1 || variant > 2)
+    return -1;
+  GemmFwdParams p;
+  p.X = dY; p.ldx = ldy; p.X2 = nullptr; p.ldx2 = 0; p.Csplit = Kred;
+  p.M = M; p.Cin = Kred; p.taps = 5;
+  p.rm = RowMap{T, T, 1, 2, 1};
+  p.W = W; p.ldw = ldw; p.Nout = Ncols; p.Npad = Ncols;
+  p.bias = nullptr; p.rowbias = nullptr; p.ldrb = 0;
+  p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
+  p.wt = 1; p.wtap = wtap; p.wcols = wtap; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on();
+  return madiff_launch_conv_taps_gnb_bf16(&p, variant, Ypre, ldyp, gamma, beta, mean, rstd, G, dgamma, dbeta, dbias, drowbias,
+                                          ldrb, stream);
+}
+
 static int wgrad_impl(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,
                       int Csplit, int M, int Cin, int taps, int T_out, int T_in, int stride, int pad, int tr, float* dW,
                       int ldw, int Nout, int accumulate, int tile, int splits, float* dbias, float* const* btab,

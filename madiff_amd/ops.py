@@ -1058,23 +1058,19 @@ def _gn_forward(y, gamma, beta, rowbias, res, n_seq, t, C, G):
     return out, stats, (n_seq, t, C, cpad, G, mode)
 
 
-def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None):
-    """-> (dy, dgamma, dbeta, dconv_bias, drowbias); parameter gradients go to the sink when one is installed."""
-    n_seq, t, C, cpad, G, mode = geom
-    dout = dout.contiguous()
-    dy = torch.empty_like(y)
+def _gn_param_bufs(gamma, beta, conv_bias, C, device):
+    """Destinations of dgamma / dbeta / dconv_bias: the live slots of the flat gradient when a sink is installed, else a
+    zeroed temporary.  -> (plist, views, bufs)"""
     plist = [gamma, beta] + ([conv_bias] if conv_bias is not None else [])
     views = [_sink_view(p_) for p_ in plist]
     tmp = None
     if any(v is None for v in views):
-        tmp = torch.zeros(len(plist), C, dtype=torch.float32, device=y.device)
+        tmp = torch.zeros(len(plist), C, dtype=torch.float32, device=device)
     bufs = [v if v is not None else tmp[i] for i, v in enumerate(views)]
-    drb = torch.empty(n_seq, C, dtype=torch.float32, device=y.device) if mode == 1 else None
-    _timed("gn_mish_bwd_rb_kernel", 0.0, lambda: lib.call(           # algorithmic bytes: read y and dout, write dy
-        "madiff_gn_mish_bwd", _dt(), y.data_ptr(), y.stride(0), dout.data_ptr(), dout.stride(0), dy.data_ptr(),
-        dy.stride(0), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-        bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr() if conv_bias is not None else None, _p(drb), C,
-        n_seq, t, C, cpad, G, _stream()), nbytes=float(3 * n_seq * t * C * y.element_size()))
+    return plist, views, bufs
+
+
+def _gn_param_outs(plist, views, bufs, conv_bias):
     outs = []
     for p_, v, b in zip(plist, views, bufs):
         if v is not None:
@@ -1084,7 +1080,79 @@ def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None):
             outs.append(b)
     if conv_bias is None:
         outs.append(None)
+    return outs
+
+
+def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None):
+    """-> (dy, dgamma, dbeta, dconv_bias, drowbias); parameter gradients go to the sink when one is installed."""
+    n_seq, t, C, cpad, G, mode = geom
+    dout = dout.contiguous()
+    dy = torch.empty_like(y)
+    plist, views, bufs = _gn_param_bufs(gamma, beta, conv_bias, C, y.device)
+    drb = torch.empty(n_seq, C, dtype=torch.float32, device=y.device) if mode == 1 else None
+    _timed("gn_mish_bwd_rb_kernel", 0.0, lambda: lib.call(           # algorithmic bytes: read y and dout, write dy
+        "madiff_gn_mish_bwd", _dt(), y.data_ptr(), y.stride(0), dout.data_ptr(), dout.stride(0), dy.data_ptr(),
+        dy.stride(0), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+        bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr() if conv_bias is not None else None, _p(drb), C,
+        n_seq, t, C, cpad, G, _stream()), nbytes=float(3 * n_seq * t * C * y.element_size()))
+    outs = _gn_param_outs(plist, views, bufs, conv_bias)
     return dy, outs[0], outs[1], outs[2], drb, dout
+
+
+FUSE_DGRAD_GN_BWD = os.environ.get("MADIFF_FUSE_DGRAD_GN_BWD", "1") != "0"
+
+
+def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0):
+    """ResidualTemporalBlock backward, middle part, as ONE launch (madiff_conv_dgrad_gn_bwd): the data gradient of
+    blocks[1]'s convolution with blocks[0]'s GroupNorm + Mish backward as its epilogue; dh never reaches memory.
+    -> (dy0, dgamma0, dbeta0, dbias0, drowbias) or None when the layer is not covered (bf16 build, k5 "same" convolution,
+    channels a multiple of 128, whole groups inside 128 channels, T <= 32)."""
+    if not FUSE_DGRAD_GN_BWD or _PRECISION != "bf16" or not dy1.is_cuda or g1.spec is not CONV5:
+        return None
+    n_seq, t, C, cpad, G, mode = geom0
+    npad = pad32(g1.osum)
+    if cpad != C or C % 128 or g1.osum != npad or npad % 64 or g1.cin != C or t > 32 or y0 is None:
+        return None
+    Cg = C // G
+    if C % G or Cg % 8 or 128 % Cg or (Cg // 8) & (Cg // 8 - 1):
+        return None
+    sig = ("dgrad_gnb", n_seq, t, C, npad, G, mode)
+    if _TUNE.get(sig) == "uncovered":
+        return None
+    Wf = _packed([w1], g1.spec, False)
+    dy0 = torch.empty(n_seq * t, C, dtype=act_dtype(), device=dy1.device)
+    drb = torch.empty(n_seq, C, dtype=torch.float32, device=dy1.device) if mode == 1 else None
+
+    def launch(variant, dst):
+        return lib.call_rc("madiff_conv_dgrad_gn_bwd", dy1.data_ptr(), dy1.stride(0), n_seq * t, npad, t, Wf.data_ptr(),
+                           Wf.stride(0), g1.cin, C, y0.data_ptr(), y0.stride(0), gamma0.data_ptr(), beta0.data_ptr(),
+                           stats0[0].data_ptr(), stats0[1].data_ptr(), G, dy0.data_ptr(), dy0.stride(0), dst[0].data_ptr(),
+                           dst[1].data_ptr(), dst[2].data_ptr() if bias0 is not None else None, _p(drb),
+                           0 if drb is None else drb.stride(0), variant, _stream())
+
+    variant = _TUNE.get(sig)
+    if variant is None and _AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+        scratch = torch.zeros(3, C, dtype=torch.float32, device=dy1.device)      # the timing launches accumulate here
+        variant = _tuned_tile(sig, (1, 2), lambda v: launch(v, scratch))
+    if variant is None or variant < 0:
+        if variant is not None and _TUNE.get(sig) == -1:
+            _TUNE[sig] = "uncovered"
+            return None
+        # not tuned (graph capture of an unseen shape / tuning disabled): fill the chip, as the fused forward does
+        variant = 2 if (npad % 128 == 0 and (-(-n_seq // (192 // t))) * (C // 128) >= 200) else 1
+    plist, views, bufs = _gn_param_bufs(gamma0, beta0, bias0, C, dy1.device)
+    rc = [0]
+
+    def run():
+        rc[0] = launch(variant, bufs)
+        return "conv_taps_bf16_kernel" if rc[0] == 0 else ""
+
+    _timed("conv_taps_bf16_kernel", g1.flops, run)
+    if rc[0]:
+        _TUNE[sig] = "uncovered"
+        return None
+    outs = _gn_param_outs(plist, views, bufs, bias0)
+    return dy0, outs[0], outs[1], outs[2], drb
 
 
 FUSE_CONV_GN = os.environ.get("MADIFF_FUSE_CONV_GN", "1") != "0"
@@ -1217,14 +1285,22 @@ class ResBlock(torch.autograd.Function):
         if dout.dtype != act_dtype():
             dout = dout.to(act_dtype())
         dy1, dgamma1, dbeta1, dbias1, _, _ = _gn_backward(y1, g1, be1, st1, geom1, dout, conv_bias=b1)
-        dh, _, _, gw1, _ = _conv_backward(cg1, h, None, [w1], [b1], dy1, True, False, [needs[9]], "none", False)
+        # blocks[1]'s data gradient with blocks[0]'s GroupNorm backward in its epilogue (one launch, no dh), else separately
+        fused = _dgrad_gn_bwd_fused(cg1, w1, dy1, y0, st0, geom0, g0, be0, b0)
+        if fused is not None:
+            _, _, _, gw1, _ = _conv_backward(cg1, h, None, [w1], [b1], dy1, False, False, [needs[9]], "none", False)
+        else:
+            dh, _, _, gw1, _ = _conv_backward(cg1, h, None, [w1], [b1], dy1, True, False, [needs[9]], "none", False)
         gwr, gbr = [None], [None]
         if rw is not None:
             dxr, dx2r, _, gwr, gbr = _conv_backward(cgr, x, x2, [rw], [rb], dout, needs[0], needs[1], [needs[13]], "colsum",
                                                    False)
         else:
             dxr, dx2r = dout, None
-        dy0, dgamma0, dbeta0, dbias0, drb, _ = _gn_backward(y0, g0, be0, st0, geom0, dh, conv_bias=b0)
+        if fused is not None:
+            dy0, dgamma0, dbeta0, dbias0, drb = fused
+        else:
+            dy0, dgamma0, dbeta0, dbias0, drb, _ = _gn_backward(y0, g0, be0, st0, geom0, dh, conv_bias=b0)
         dx, dx2, _, gw0, _ = _conv_backward(cg0, x, x2, [w0], [b0], dy0, needs[0], needs[1], [needs[5]], "none", False,
                                             addends=(dxr, dx2r))
         return (dx, dx2, drb if needs[2] else None, None, None, gw0[0], dbias0, dgamma0, dbeta0, gw1[0], dbias1, dgamma1,

@@ -72,16 +72,20 @@ def test_folded_loss_and_gradient_match_accumulation(prec, name, discrete, share
                         dropout_mask=torch.cat([d["dropout_mask"] for d in dr]))
     if prec == "fp32" and hh == 0:
         assert abs(float(whole) - float(mean)) > 1e-4 * abs(float(mean))
-    worst = 0.0
+    worst, worst_k = 0.0, None
     for k, p in dif.named_parameters():
         if k not in ref:
             continue
+        if ("key_layer.bias" in k or "key_time_mlp" in k) and prec == "bf16":
+            continue      # analytically zero (softmax shift invariance): in bf16 these gradients are rounding noise
         den = float(ref[k].abs().max())
         if den < 1e-9:
             continue
-        worst = max(worst, float((p.grad - ref[k]).abs().max()) / den)
+        err = float((p.grad - ref[k]).abs().max()) / den
+        if err > worst:
+            worst, worst_k = err, k
     # (bf16: GroupNorm statistics are per sample, so folding only reorders fp32 sums inside the weight-gradient GEMMs)
-    assert worst < (2e-4 if prec == "fp32" else 6e-2), worst
+    assert worst < (2e-4 if prec == "fp32" else 6e-2), (worst, worst_k)
 
 
 def test_graphed_step_folds_and_matches_unfolded_steps(prec):
