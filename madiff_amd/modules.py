@@ -367,7 +367,7 @@ class TemporalUnet(nn.Module):
         blocks = self.rtb_blocks()
         layers = [b.time_mlp[1] for b in blocks]
         proj_all = conv_gemm(mish(temb), [l.weight for l in layers], [l.bias for l in layers], LINEAR, 1, perm="f32")
-        bproj = list(ops.SplitCols.apply(proj_all, tuple(b.out_channels for b in blocks)))
+        bproj = ops.split_cols(proj_all, tuple(b.out_channels for b in blocks))
         bi = 0
         h, t = xcl, t_len
         skips = []
@@ -462,7 +462,7 @@ class SharedConvAttentionDeconv(nn.Module):
         blocks, layers, n_attn = self._time_layers()
         proj_all = conv_gemm(mish(temb), [l.weight for l in layers], [l.bias for l in layers], LINEAR, 1, perm="f32")
         sizes = [b.out_channels for b in blocks] + [2 * self.self_attn[i].cq + self.self_attn[i].cv for i in range(n_attn)]
-        views = list(ops.SplitCols.apply(proj_all, tuple(sizes)))
+        views = ops.split_cols(proj_all, tuple(sizes))
         bproj, aproj = views[: len(blocks)], views[len(blocks):]
         bi = 0
         h, t = xcl, t_len

@@ -1083,18 +1083,24 @@ def _gn_param_outs(plist, views, bufs, conv_bias):
     return outs
 
 
-def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None):
-    """-> (dy, dgamma, dbeta, dconv_bias, drowbias); parameter gradients go to the sink when one is installed."""
+def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None, drb_slot=None):
+    """-> (dy, dgamma, dbeta, dconv_bias, drowbias); parameter gradients go to the sink when one is installed.
+    drb_slot: grad_slot() of the row-bias tensor: its gradient is then written straight into the shared buffer."""
     n_seq, t, C, cpad, G, mode = geom
     dout = dout.contiguous()
     dy = torch.empty_like(y)
     plist, views, bufs = _gn_param_bufs(gamma, beta, conv_bias, C, y.device)
-    drb = torch.empty(n_seq, C, dtype=torch.float32, device=y.device) if mode == 1 else None
+    drb = None
+    if mode == 1:
+        drb = slot_view(drb_slot, n_seq, C)
+        if drb is None:
+            drb = torch.empty(n_seq, C, dtype=torch.float32, device=y.device)
     _timed("gn_mish_bwd_rb_kernel", 0.0, lambda: lib.call(           # algorithmic bytes: read y and dout, write dy
         "madiff_gn_mish_bwd", _dt(), y.data_ptr(), y.stride(0), dout.data_ptr(), dout.stride(0), dy.data_ptr(),
         dy.stride(0), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-        bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr() if conv_bias is not None else None, _p(drb), C,
-        n_seq, t, C, cpad, G, _stream()), nbytes=float(3 * n_seq * t * C * y.element_size()))
+        bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr() if conv_bias is not None else None, _p(drb),
+        C if drb is None else drb.stride(0), n_seq, t, C, cpad, G, _stream()),
+        nbytes=float(3 * n_seq * t * C * y.element_size()))
     outs = _gn_param_outs(plist, views, bufs, conv_bias)
     return dy, outs[0], outs[1], outs[2], drb, dout
 
@@ -1102,7 +1108,7 @@ def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None):
 FUSE_DGRAD_GN_BWD = os.environ.get("MADIFF_FUSE_DGRAD_GN_BWD", "1") != "0"
 
 
-def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0):
+def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, drb_slot=None):
     """ResidualTemporalBlock backward, middle part, as ONE launch (madiff_conv_dgrad_gn_bwd): the data gradient of
     blocks[1]'s convolution with blocks[0]'s GroupNorm + Mish backward as its epilogue; dh never reaches memory.
     -> (dy0, dgamma0, dbeta0, dbias0, drowbias) or None when the layer is not covered (bf16 build, k5 "same" convolution,
@@ -1121,7 +1127,11 @@ def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0):
         return None
     Wf = _packed([w1], g1.spec, False)
     dy0 = torch.empty(n_seq * t, C, dtype=act_dtype(), device=dy1.device)
-    drb = torch.empty(n_seq, C, dtype=torch.float32, device=dy1.device) if mode == 1 else None
+    drb = None
+    if mode == 1:
+        drb = slot_view(drb_slot, n_seq, C)
+        if drb is None:
+            drb = torch.empty(n_seq, C, dtype=torch.float32, device=dy1.device)
 
     def launch(variant, dst):
         return lib.call_rc("madiff_conv_dgrad_gn_bwd", dy1.data_ptr(), dy1.stride(0), n_seq * t, npad, t, Wf.data_ptr(),
@@ -1274,6 +1284,7 @@ class ResBlock(torch.autograd.Function):
         out, y1, st1, cg1, geom1 = block(h, None, None, res, w1, b1, g1, be1)
         ctx.save_for_backward(x, x2, y0, st0, h, y1, st1, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb)
         ctx.geo = (cg0, geom0, cgr, cg1, geom1)
+        ctx.temb_slot = grad_slot(temb)
         return out
 
     @staticmethod
@@ -1286,7 +1297,7 @@ class ResBlock(torch.autograd.Function):
             dout = dout.to(act_dtype())
         dy1, dgamma1, dbeta1, dbias1, _, _ = _gn_backward(y1, g1, be1, st1, geom1, dout, conv_bias=b1)
         # blocks[1]'s data gradient with blocks[0]'s GroupNorm backward in its epilogue (one launch, no dh), else separately
-        fused = _dgrad_gn_bwd_fused(cg1, w1, dy1, y0, st0, geom0, g0, be0, b0)
+        fused = _dgrad_gn_bwd_fused(cg1, w1, dy1, y0, st0, geom0, g0, be0, b0, ctx.temb_slot)
         if fused is not None:
             _, _, _, gw1, _ = _conv_backward(cg1, h, None, [w1], [b1], dy1, False, False, [needs[9]], "none", False)
         else:
@@ -1300,7 +1311,8 @@ class ResBlock(torch.autograd.Function):
         if fused is not None:
             dy0, dgamma0, dbeta0, dbias0, drb = fused
         else:
-            dy0, dgamma0, dbeta0, dbias0, drb, _ = _gn_backward(y0, g0, be0, st0, geom0, dh, conv_bias=b0)
+            dy0, dgamma0, dbeta0, dbias0, drb, _ = _gn_backward(y0, g0, be0, st0, geom0, dh, conv_bias=b0,
+                                                                drb_slot=ctx.temb_slot)
         dx, dx2, _, gw0, _ = _conv_backward(cg0, x, x2, [w0], [b0], dy0, needs[0], needs[1], [needs[5]], "none", False,
                                             addends=(dxr, dx2r))
         return (dx, dx2, drb if needs[2] else None, None, None, gw0[0], dbias0, dgamma0, dbeta0, gw1[0], dbias1, dgamma1,
@@ -1398,6 +1410,7 @@ class AttnBlock(torch.autograd.Function):
             nbytes=float(B * A * T * (2 * Cq + 3 * C) * x.element_size()))
         ctx.save_for_backward(x, qkv, gamma, *weights, *biases)
         ctx.g, ctx.geom, ctx.has_rb = g, (B, A, T, H, Cq, C, residual), time_proj is not None
+        ctx.rb_slot = grad_slot(time_proj) if time_proj is not None else None
         return out
 
     @staticmethod
@@ -1415,7 +1428,11 @@ class AttnBlock(torch.autograd.Function):
             dqkv[:, ncol:].zero_()
         view = _sink_view(gamma) if residual else None
         dgamma = view if view is not None else (torch.zeros(1, dtype=torch.float32, device=qkv.device) if residual else None)
-        drb = torch.empty(B * A, ncol, dtype=torch.float32, device=qkv.device) if (ctx.has_rb and needs[1]) else None
+        drb = None
+        if ctx.has_rb and needs[1]:
+            drb = slot_view(ctx.rb_slot, B * A, ncol)
+            if drb is None:
+                drb = torch.empty(B * A, ncol, dtype=torch.float32, device=qkv.device)
         _timed("attn_bwd_v2_kernel", 0.0, lambda: lib.call(
             "madiff_attn_bwd_rb", _dt(), qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0), dqkv.data_ptr(),
             dqkv.stride(0), _p(gamma), _p(dgamma), _p(drb), 0 if drb is None else drb.stride(0), B, A, T, H, Cq, C,
@@ -1473,8 +1490,39 @@ class PackTraj(torch.autograd.Function):
         return unpack_traj(d, B, T, A, F)
 
 
+class _GradHolder:
+    """Gradient buffer of a SplitCols input, shared with the consumers of its column blocks: a consumer whose backward
+    kernel can write its block's gradient with a row stride (the row-bias gradients of GroupNorm / attention backward)
+    asks for its slice and writes there, and SplitCols.backward then hands the buffer on without a concatenation."""
+
+    def __init__(self, n, total, dtype, device):
+        self.n, self.total, self.dtype, self.device = n, total, dtype, device
+        self.buf = None
+
+    def view(self, off, width):
+        if self.buf is None:
+            self.buf = torch.zeros(self.n, self.total, dtype=self.dtype, device=self.device)
+        return self.buf[:, off:off + width]
+
+
+def grad_slot(t):
+    """(holder, offset, width) when `t` is a column block made by split_cols whose gradient may be written in place."""
+    return getattr(t, "_madiff_slot", None)
+
+
+def slot_view(slot, n_rows, width):
+    """The destination view of a slot if it fits what the kernel will write ([n_rows, width] fp32, 16-byte aligned), else None."""
+    if slot is None:
+        return None
+    holder, off, w = slot
+    if w != width or holder.n != n_rows or holder.dtype != torch.float32 or off % 4 or holder.total % 4:
+        return None
+    return holder.view(off, width)
+
+
 class SplitCols(torch.autograd.Function):
-    """Views of column blocks of one fp32 matrix (the fused time-MLP output); backward concatenates."""
+    """Views of column blocks of one fp32 matrix (the fused time-MLP output); backward hands on the shared gradient buffer
+    the consumers wrote their blocks into (_GradHolder), or concatenates what it was given."""
 
     @staticmethod
     def forward(ctx, big, sizes):
@@ -1485,16 +1533,40 @@ class SplitCols(torch.autograd.Function):
             outs.append(big[:, off:off + s])
             off += s
         ctx.total = big.shape[1]
+        ctx.holder = _GradHolder(big.shape[0], big.shape[1], big.dtype, big.device)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         n, dt, dev = ctx.meta
+        holder, buf = ctx.holder, ctx.holder.buf
+        holder.buf = None                      # one buffer per backward pass
+        if buf is not None:
+            off, es = 0, buf.element_size()
+            for g, s in zip(grads, ctx.sizes):
+                if g is not None and not (g.data_ptr() == buf.data_ptr() + off * es and g.shape == (n, s)
+                                          and g.stride() == (ctx.total, 1)):
+                    buf[:, off:off + s].copy_(g)         # a consumer that did not use its slot
+                off += s
+            return buf, None
         parts = [g if g is not None else torch.zeros(n, s, dtype=dt, device=dev) for g, s in zip(grads, ctx.sizes)]
         used = sum(ctx.sizes)
         if ctx.total > used:
             parts.append(torch.zeros(n, ctx.total - used, dtype=dt, device=dev))
         return torch.cat(parts, dim=1), None
+
+
+def split_cols(big, sizes):
+    """SplitCols.apply + tags on the outputs that let their consumers write gradients in place (training only)."""
+    outs = list(SplitCols.apply(big, tuple(sizes)))
+    node = outs[0].grad_fn if outs else None
+    holder = getattr(node, "holder", None)
+    if holder is not None:
+        off = 0
+        for o, s_ in zip(outs, sizes):
+            o._madiff_slot = (holder, off, s_)
+            off += s_
+    return outs
 
 
 def sinusoid(ts: torch.Tensor, freq: torch.Tensor, n_agents: int) -> torch.Tensor:
