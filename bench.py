@@ -91,7 +91,10 @@ def build(device):
 
 KERNEL_DESC = {
     "conv_taps_bf16_kernel": "conv_taps_bf16_kernel<WM, WT, D> (all-taps k5 implicit-GEMM convolution: forward + data-gradient "
-                             "launches of the stride-1 k5 layers, both tile instantiations)",
+                             "launches of the stride-1 k5 layers incl. the fused GroupNorm+Mish forward epilogue, both tile instantiations; the "
+                             "data-gradient launches that also run a GroupNorm backward are the <GNB> family)",
+    "conv_taps_bf16_kernel<GNB>": "conv_taps_bf16_kernel<.., GNB = true> (k5 data gradient with the preceding block's GroupNorm+Mish "
+                                  "backward as its epilogue)",
     "gemm_fwd_bf16_kernel": "gemm_fwd_bf16_kernel<OutT, BM, BN, WT, D> (LDS-DMA implicit-GEMM conv/linear: forward + "
                             "data-gradient launches of the 1x1 / strided / linear layers, all tile instantiations)",
     "gemm_wgrad_taps_bf16_kernel": "gemm_wgrad_taps_bf16_kernel<BO, BC, 5, NQ, D> (all-taps k5 weight gradient)",
@@ -420,7 +423,10 @@ def main():
         for k, v in summ.items():
             rec = {"launches_per_step": v["launches"] / args.steps, "avg_us": 1e3 * v["ms"] / v["launches"],
                    "share_of_step": v["ms"] / (dt * 1e3)}
-            if v.get("bytes", 0.0) > 0:          # HBM-bound family: algorithmic bytes / measured time against 8 TB/s
+            if v.get("bytes", 0.0) > 0 and v.get("flops", 0.0) > 0:      # a fused launch: MFMA work + an HBM-bound epilogue
+                rec.update({"bound": "mfma", "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                            "epilogue_algorithmic_mb_per_launch": v["bytes"] / v["launches"] / 1e6})
+            elif v.get("bytes", 0.0) > 0:        # HBM-bound family: algorithmic bytes / measured time against 8 TB/s
                 gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
                 rec.update({"bound": "hbm", "algorithmic_mb_per_launch": v["bytes"] / v["launches"] / 1e6, "gbps": gbs,
                             "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})

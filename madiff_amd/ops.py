@@ -1155,9 +1155,11 @@ def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, dr
 
     def run():
         rc[0] = launch(variant, bufs)
-        return "conv_taps_bf16_kernel" if rc[0] == 0 else ""
+        return "conv_taps_bf16_kernel<GNB>" if rc[0] == 0 else ""
 
-    _timed("conv_taps_bf16_kernel", g1.flops, run)
+    # its own family in the timing records (rocprofv3 shows it as the GNB = true instantiation): the launch carries the
+    # data gradient's FLOPs plus the GroupNorm backward's traffic (read y, write dy; dh stays on chip)
+    _timed("conv_taps_bf16_kernel<GNB>", g1.flops, run, nbytes=float(2 * n_seq * t * C * dy1.element_size()))
     if rc[0]:
         _TUNE[sig] = "uncovered"
         return None
