@@ -1502,8 +1502,8 @@ class _GradHolder:
         self.buf = None
 
     def view(self, off, width):
-        if self.buf is None:
-            self.buf = torch.zeros(self.n, self.total, dtype=self.dtype, device=self.device)
+        if self.buf is None:          # not zero-filled: SplitCols.backward defines every column nobody wrote
+            self.buf = torch.empty(self.n, self.total, dtype=self.dtype, device=self.device)
         return self.buf[:, off:off + width]
 
 
@@ -1546,10 +1546,13 @@ class SplitCols(torch.autograd.Function):
         if buf is not None:
             off, es = 0, buf.element_size()
             for g, s in zip(grads, ctx.sizes):
-                if g is not None and not (g.data_ptr() == buf.data_ptr() + off * es and g.shape == (n, s)
-                                          and g.stride() == (ctx.total, 1)):
+                if g is None:
+                    buf[:, off:off + s].zero_()          # a block without a consumer
+                elif not (g.data_ptr() == buf.data_ptr() + off * es and g.shape == (n, s) and g.stride() == (ctx.total, 1)):
                     buf[:, off:off + s].copy_(g)         # a consumer that did not use its slot
                 off += s
+            if ctx.total > off:
+                buf[:, off:].zero_()                     # pad columns
             return buf, None
         parts = [g if g is not None else torch.zeros(n, s, dtype=dt, device=dev) for g, s in zip(grads, ctx.sizes)]
         used = sum(ctx.sizes)
