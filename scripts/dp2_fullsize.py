@@ -74,10 +74,12 @@ if __name__ == "__main__":
     dif, batch, draws = setup()
     p0, p1, loss, nb, dp = steps(dif, batch, draws)
     assert not dp
-    mv_single, mv_dp = (p1 - p0).double(), (a - p0).double()
-    rel = float((mv_dp - mv_single).norm() / mv_single.norm())
-    cos = float((mv_dp * mv_single).sum() / (mv_dp.norm() * mv_single.norm()))
+    # explicit float64 sums on the host (round 1 printed a cosine of 1.002: Tensor.norm() on a 64 M element tensor)
+    mv_single, mv_dp = (p1.cpu().double() - p0.cpu().double()), (a.cpu().double() - p0.cpu().double())
+    n_s, n_d = float((mv_single * mv_single).sum()) ** 0.5, float((mv_dp * mv_dp).sum()) ** 0.5
+    rel = float(((mv_dp - mv_single) ** 2).sum()) ** 0.5 / n_s
+    cos = float((mv_dp * mv_single).sum()) / (n_d * n_s)
     print(f"parameter movement after 6 steps, 2-rank DP vs single process: relative L2 difference {rel:.4f}, cosine {cos:.5f}; "
-          f"|movement| {float(mv_single.norm()):.4f}", flush=True)
-    assert torch.equal(a, b) and cos > 0.98
+          f"|movement| {n_s:.4f}", flush=True)
+    assert torch.equal(a, b) and 0.98 < cos <= 1.0 + 1e-12
     print("OK")
