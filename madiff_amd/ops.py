@@ -465,6 +465,18 @@ if _TUNE_CACHE:
     atexit.register(lambda: save_tune_cache(_TUNE_CACHE))
 
 
+def _time_calls(fn, reps: int = 5) -> float:
+    """Milliseconds for `reps` calls of fn on the current stream (tuning decisions, never under capture)."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
 def _tuned_tile(sig, candidates, launch) -> int:
     """Output tile of the LDS-DMA GEMM for one layer shape.  The first time a shape is seen (outside graph capture)
     every tile the library offers is timed on the real operands and the fastest is remembered; results do not depend
@@ -1141,9 +1153,27 @@ def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, dr
                            0 if drb is None else drb.stride(0), variant, _stream())
 
     variant = _TUNE.get(sig)
+    if _TUNE.get(sig + ("use",)) is False:      # measured: data gradient + standalone GroupNorm backward is faster here
+        return None
     if variant is None and _AUTOTUNE and not torch.cuda.is_current_stream_capturing():
         scratch = torch.zeros(3, C, dtype=torch.float32, device=dy1.device)      # the timing launches accumulate here
         variant = _tuned_tile(sig, (1, 2), lambda v: launch(v, scratch))
+        if variant >= 0:
+
+            def unfused():
+                dh = _dgrad_wt(dy1, n_seq * t, npad, g1.spec, t, t, Wf, g1.cin, 0, C, C)
+                if dh is not None:
+                    lib.call("madiff_gn_mish_bwd", _dt(), y0.data_ptr(), y0.stride(0), dh.data_ptr(), dh.stride(0),
+                             dy0.data_ptr(), dy0.stride(0), gamma0.data_ptr(), beta0.data_ptr(), stats0[0].data_ptr(),
+                             stats0[1].data_ptr(), scratch[0].data_ptr(), scratch[1].data_ptr(),
+                             scratch[2].data_ptr() if bias0 is not None else None, _p(drb),
+                             C if drb is None else drb.stride(0), n_seq, t, C, cpad, G, _stream())
+
+            unfused()
+            t_fused, t_plain = _time_calls(lambda: launch(variant, scratch), 20), _time_calls(unfused, 20)
+            _TUNE[sig + ("use",)] = bool(t_fused <= t_plain)
+            if t_fused > t_plain:
+                return None
     if variant is None or variant < 0:
         if variant is not None and _TUNE.get(sig) == -1:
             _TUNE[sig] = "uncovered"
@@ -1207,12 +1237,33 @@ def _conv_block_fused(x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w,
                            _stream())
 
     sig = ("convgn", M, cin, O, t_in, G, mode, need_y, x2 is not None)
+    if _TUNE.get(sig + ("use",)) is False:      # measured: convolution + standalone GroupNorm is faster for this shape
+        return None
     variant = _tuned_tile(sig, (1, 2), launch)
     if variant < 0:
         if _TUNE.get(sig) == -1:   # tuned before: no fused variant covers this layer
             return None
         # not tuned (graph capture of an unseen shape / tuning disabled): fill the chip
         variant = 2 if (-(-n_seq // (192 // t_in))) * (O // 128) >= 200 else 1
+    elif _TUNE.get(sig + ("use",)) is None and _AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+        # fused or not?  With few sequences (small batches) the epilogue runs on a handful of workgroups and the
+        # convolution's best tile is a small one: time the fused launch against convolution + standalone GroupNorm once
+        # (bare library calls on preallocated outputs: the host must stay ahead of ~40 us kernels for the comparison to
+        # be about the GPU)
+        yy, oo = torch.empty(M, O, dtype=act_dtype(), device=x.device), torch.empty(M, O, dtype=act_dtype(), device=x.device)
+        st = torch.empty(2, n_seq * G, dtype=torch.float32, device=x.device)
+
+        def unfused():
+            _gemm(x, x2, c1, M, cin, spec, t_in, t_in, spec.tr, W, O, O, b, None, yy, 0, None)
+            lib.call("madiff_gn_mish_fwd", _dt(), yy.data_ptr(), yy.stride(0), oo.data_ptr(), oo.stride(0), gamma.data_ptr(),
+                     beta.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), n_seq, t_in, O, O, G, 1e-5, mode, _p(rowbias),
+                     0 if rowbias is None else rowbias.stride(0), _p(res), 0 if res is None else res.stride(0), _stream())
+
+        unfused()                                # (tunes the plain convolution's tile on first use)
+        t_fused, t_plain = _time_calls(lambda: launch(variant), 20), _time_calls(unfused, 20)
+        _TUNE[sig + ("use",)] = bool(t_fused <= t_plain)
+        if t_fused > t_plain:
+            return None
     g = _Geom()
     g.flops = 2.0 * M * O * I * spec.taps
     rc = [0]
