@@ -28,6 +28,7 @@ class DevicePlanner:
         self.decentralized = bool(decentralized_execution)
         self.max_path_length = max_path_length
         self._buf = {}
+        self._hist = None
 
     # ------------------------------------------------------------------ conditions (evaluator.py:50-132)
     def _buffers(self, B: int, device):
@@ -63,6 +64,27 @@ class DevicePlanner:
             idx = torch.arange(self.A, device=obs.device)
             v[:, idx, : self.hh + 1, idx] = obs.permute(2, 0, 1, 3)      # copy a, agent a <- agent a's history
         return {"x": cx, "masks": b["masks"]}
+
+    # ------------------------------------------------------------------ observation history (evaluator.py:259-275)
+    def reset_history(self, first_obs: torch.Tensor, use_zero_padding: bool = True) -> None:
+        """Start an episode batch: the evaluator's `deque(maxlen=history_horizon + 1)` pre-filled with history_horizon
+        entries -- zeros (`use_zero_padding`) or copies of the first normalised observation [B, A, F] -- kept on the
+        device as one [B, hh+1, A, F] buffer (slot 0 is overwritten by the first push)."""
+        B = first_obs.shape[0]
+        assert first_obs.shape[1:] == (self.A, self.F), first_obs.shape
+        h = torch.zeros(B, self.hh + 1, self.A, self.F, device=first_obs.device, dtype=torch.float32)
+        if not use_zero_padding and self.hh > 0:
+            h[:, 1:] = first_obs.to(torch.float32).unsqueeze(1)
+        self._hist = h
+
+    def push_obs(self, obs: torch.Tensor) -> torch.Tensor:
+        """`obs_queue.append(obs); np.stack(list(obs_queue), axis=1)` (evaluator.py:273-275) on the device: drops the
+        oldest entry, appends the normalised observation [B, A, F], returns the history [B, hh+1, A, F] (newest last)."""
+        h = self._hist
+        if self.hh > 0:
+            h[:, :-1] = h[:, 1:].clone()
+        h[:, -1] = obs.to(h.dtype)
+        return h
 
     # ------------------------------------------------------------------ sampling (evaluator.py:85-134)
     @torch.no_grad()

@@ -69,6 +69,27 @@ def test_planner_conditions_match_oracle(decentralized, hh):
         obs = obs * 0.5 + 1.0
 
 
+@pytest.mark.parametrize("zero_pad", [True, False])
+@pytest.mark.parametrize("hh", [0, 3])
+def test_observation_history_matches_evaluator_queue(zero_pad, hh):
+    """The evaluator's deque (evaluator.py:263-275): maxlen hh + 1, pre-filled with hh zeros or hh copies of the first
+    normalised observation; each environment step appends and stacks."""
+    from collections import deque
+    from madiff_amd.planner import DevicePlanner
+    A, F, B = 3, 4, 2
+    rng = np.random.default_rng(3)
+    obs_seq = [rng.normal(size=(B, A, F)).astype(np.float32) for _ in range(6)]
+    q = deque(maxlen=hh + 1)
+    q.extend([np.zeros_like(obs_seq[0]) if zero_pad else obs_seq[0] for _ in range(hh)])
+    pl = DevicePlanner(_Shape(A, 5, hh, F), False)
+    pl.reset_history(torch.from_numpy(obs_seq[0]), use_zero_padding=zero_pad)
+    for o in obs_seq:
+        q.append(o)
+        ref = np.stack(list(q), axis=1)
+        got = pl.push_obs(torch.from_numpy(o))
+        assert np.array_equal(got.numpy(), ref)
+
+
 def test_update_return_to_go():
     from madiff_amd.planner import DevicePlanner
     rtg = torch.rand(5, 1, 3)
