@@ -76,6 +76,13 @@ int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, const void* 
                     int taps, int T_out, int T_in, int stride, int pad, int tr, const void* W, int ldw, int Nout, int Npad,
                     const float* bias, const float* rowbias, int ldrb, void* C, int ldc, int act, int permT, int permA,
                     int tile, madiff_stream_t stream);
+/* Workspace for the all-taps k5 kernel's reduction split (no counterpart in the reference): with it registered, layers whose
+   output tiles would leave most of the chip idle (small batches: batch 32 x accumulate 2 training, the evaluator's 10
+   environments) are cut into slices of the input channels; partial tiles meet in `ws` and the last workgroup to arrive
+   finishes the tile (bias / GroupNorm epilogues unchanged, summation order fixed).  ws: device memory, 16-byte aligned,
+   `bytes` long; counters: n_counters zeroed ints (they reset themselves).  One registration per device (the current one);
+   ws = NULL unregisters.  Launches using it must be stream-ordered on that GPU. */
+int madiff_set_splitk_workspace(void* ws, long bytes, int* counters, int n_counters);
 int madiff_gemm_tile_count(void);
 /* rows / columns / LDS stages of variant `tile`; returns 1 when madiff_gemm_dgrad_wt offers it too, 0 when not, -1 when
  * the id is invalid. */

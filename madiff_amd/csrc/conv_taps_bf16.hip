@@ -89,6 +89,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   int bx = blockIdx.x, by = blockIdx.y;
   xcd_remap(bx, by, p.xcd);
   const int m0 = bx * rows_used, n0 = by * 128;
+  const int cbase = p.cks > 1 ? (int)blockIdx.z * ((p.Cin >> 6) / p.cks) : 0;
 
   for (int i = tid; i < 512; i += NT) ((float*)(smem + (i >> 8) * A_BYTES + A_TILE))[i & 255] = 0.f;   // zero rows
 
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
   auto issueA = [&](int c) {
-    int c0 = c << 6;
+    int c0 = (c + cbase) << 6;
     const unsigned char* xb = (const unsigned char*)p.X;
     const bool second = c0 >= p.Csplit;
     if (second) { xb = (const unsigned char*)p.X2; c0 -= p.Csplit; }
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   };
   auto issueW = [&](int tap, int c, int slot) {
     const unsigned char* wb = (const unsigned char*)p.W +
-                              (WT ? ((size_t)(c << 6) * p.ldw + (size_t)tap * p.wtap) * 2 : ((size_t)tap * p.Cin + (c << 6)) * 2);
+                              (WT ? ((size_t)((c + cbase) << 6) * p.ldw + (size_t)tap * p.wtap) * 2
+                                  : ((size_t)tap * p.Cin + ((c + cbase) << 6)) * 2);
     const unsigned base = lds0 + 2 * A_BYTES + slot * W_BYTES + WP * wave * 1024;
 #pragma unroll
     for (int j = 0; j < WP; j++) ct_dma16(wb, w_off[j], base + j * 1024);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
 
   // ---- software pipeline.  Invariant at the top of step s = (c, tap): the kh = 0 fragments of step s are (being) loaded
   // into a0/b0, W(s) and A(c) are visible to every wave, W(s+1) .. W(s+D-2) are in flight.
-  const int nc = p.Cin >> 6;
+  const int nc = p.cks > 1 ? (p.Cin >> 6) / p.cks : (p.Cin >> 6);      // channel chunks of this workgroup's slice
   bf16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
   __syncthreads();                         // zero rows written before any fragment read
   if constexpr (D == 5) {
@@ -313,6 +315,42 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       slot = nslot;
     }
   }
+  }
+
+  if (p.cks > 1) {
+    // ---- reduction split: partial tiles meet in the workspace, the last slice to arrive finishes the tile.  Every thread
+    // stores / reloads its own accumulator registers (16-byte vectors, coalesced), so no layout change is involved; the
+    // sum runs over the slices in order, whoever is last, so results do not depend on arrival order.
+    __shared__ int ticket;
+    const int tile_id = by * gridDim.x + bx;
+    constexpr int PART = NT * MI * NJ * 4;                     // floats per partial tile
+    float* wsb = p.ws + (size_t)tile_id * p.cks * PART;
+    float* mine = wsb + (size_t)blockIdx.z * PART;
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) *(f32x4*)(mine + ((i * NJ + j) * NT + tid) * 4) = acc[i][j];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) ticket = atomicAdd(&p.ws_cnt[tile_id], 1);
+    __syncthreads();
+    if (ticket != p.cks - 1) return;
+    __threadfence();
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.cks; z++) {
+      const float* src = wsb + (size_t)z * PART;
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const f32x4 v = __builtin_nontemporal_load((const f32x4*)(src + ((i * NJ + j) * NT + tid) * 4));
+          acc[i][j] += v;
+        }
+    }
+    if (tid == 0) p.ws_cnt[tile_id] = 0;                       // ready for the next launch
   }
 
   if constexpr (GN) {
@@ -649,6 +687,25 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   }
 }
 
+// Reduction split of the all-taps kernel (p.cks, see gemm_params.h): only for layers whose output tiles leave most of the
+// chip idle; the slices must hold whole chunks (an even number of them for the two-steps-per-barrier variant) and the
+// partial tiles must fit the registered workspace.
+static int ct_pick_cks(const GemmFwdParams& p, long tiles, int variant) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MADIFF_CONV_SPLITK"); on = e ? atoi(e) : 1; }
+  if (!on || !p.ws || !p.ws_cnt || tiles >= 128 || tiles > p.ws_ncnt) return 1;
+  const int nc = p.Cin >> 6, nt = variant == 1 ? 256 : 512;
+  int best = 1;
+  for (int k = 2; k <= nc / 2; k++) {
+    if (nc % k) continue;
+    const int per = nc / k;
+    if (variant == 2 && (per & 1)) continue;
+    if (tiles * k > 512 || tiles * k * nt * 48 > p.ws_floats) break;
+    best = k;
+  }
+  return best;
+}
+
 // variant: 0 = 192-row tile (8 waves), 1 = 96-row tile (4 waves).  Returns 1 when the layer is not covered.
 extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_bf16(const void* params, int out_f32, int variant,
                                                                                   hipStream_t stream) {
@@ -675,6 +732,8 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_bf1
   const int n_seq = p.M / T;
   const int shift0 = p.rm.tr ? p.rm.pad : -p.rm.pad, shift_step = p.rm.tr ? -1 : 1;
   dim3 grid((n_seq + spt - 1) / spt, (p.Npad + 127) / 128);
+  p.cks = ct_pick_cks(p, (long)grid.x * grid.y, variant);
+  grid.z = p.cks;
   GnEpi ge = {};
 #define CT_LAUNCH(WM_, WT_, D_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, WT_, D_, false>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, shift0, shift_step, ge)
   if (variant == 2) {          // 192 rows, 5-deep W ring, one barrier per two (chunk, tap) steps
@@ -724,6 +783,8 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_
   const int spt = BM / T, rows_used = spt * T;
   const int n_seq = p.M / T;
   dim3 grid((n_seq + spt - 1) / spt, p.Nout / 128);
+  p.cks = ct_pick_cks(p, (long)grid.x * grid.y, variant);
+  grid.z = p.cks;
   // epilogue geometry: VPL = ceil(T / 4) row iterations per lane, 8 / VPL sequences per wave must cover the tile's share
   const int vpl = (T + 3) / 4, nw = variant == 1 ? 4 : 8;
   if ((spt + nw - 1) / nw > 8 / vpl) return 1;
@@ -781,6 +842,8 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gnb
   const int spt = BM / T, rows_used = spt * T;
   const int n_seq = p.M / T;
   dim3 grid((n_seq + spt - 1) / spt, p.Nout / 128);
+  p.cks = ct_pick_cks(p, (long)grid.x * grid.y, variant);
+  grid.z = p.cks;
   const int vpl = (T + 3) / 4, nw = variant == 1 ? 4 : 8;
   if ((spt + nw - 1) / nw > 8 / vpl) return 1;
 #define CT_GNB(WM_, D_, V_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, true, D_, false, V_, true>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, 2, -1, ge)

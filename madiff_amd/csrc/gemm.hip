@@ -386,6 +386,31 @@ static int pick_tile(int M, int Npad, int wt) {
   return best >= 1 ? best + 6 : best;      // three LDS stages for every shape but 128x128 (one workgroup per CU there)
 }
 
+// ---- workspace of the all-taps kernel's reduction split (conv_taps_bf16.hip, p.cks): registered once per device by the
+// host (madiff_amd/ops.py allocates 64 MB + 4096 zeroed counters on first use).  The counters reset themselves; launches
+// that use the workspace must be ordered on the GPU (the product issues every all-taps launch on the step's main stream).
+#define MADIFF_MAX_DEV 64
+static float* g_ws[MADIFF_MAX_DEV];
+static long g_ws_floats[MADIFF_MAX_DEV];
+static int* g_ws_cnt[MADIFF_MAX_DEV];
+static int g_ws_ncnt[MADIFF_MAX_DEV];
+
+extern "C" int madiff_set_splitk_workspace(void* ws, long bytes, int* counters, int n_counters) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MADIFF_MAX_DEV) return -1;
+  if (ws && (((size_t)ws % 16) || bytes < 0 || !counters || n_counters <= 0)) return -1;
+  g_ws[dev] = (float*)ws; g_ws_floats[dev] = ws ? bytes / 4 : 0; g_ws_cnt[dev] = ws ? counters : nullptr;
+  g_ws_ncnt[dev] = ws ? n_counters : 0;
+  return 0;
+}
+
+static void attach_ws(GemmFwdParams& p) {
+  int dev = -1;
+  p.ws = nullptr; p.ws_floats = 0; p.ws_cnt = nullptr; p.ws_ncnt = 0; p.cks = 1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MADIFF_MAX_DEV) return;
+  p.ws = g_ws[dev]; p.ws_floats = g_ws_floats[dev]; p.ws_cnt = g_ws_cnt[dev]; p.ws_ncnt = g_ws_ncnt[dev];
+}
+
 static int xcd_on() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MADIFF_XCD_REMAP"); v = e ? (atoi(e) != 0) : 1; }
@@ -423,7 +448,7 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Npad; p.bias = bias; p.rowbias = rowbias; p.ldrb = ldrb;
   p.C = C; p.ldc = ldc; p.act = act; p.permT = permT; p.permA = permA;
-  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on();
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p);
   dim3 grid((M + 127) / 128, (Npad + 127) / 128), block(256);
   if (tile >= kFirstTapsTile) {
     if (dtype != MADIFF_BF16 || !use_dma_kernel()) return 1;
@@ -462,7 +487,7 @@ extern "C" int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, i
   p.rm = RowMap{T, T, 1, 2, 0};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Nout; p.bias = bias; p.rowbias = nullptr; p.ldrb = 0;
   p.C = Y; p.ldc = ldy; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on();
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p);
   return madiff_launch_conv_taps_gn_bf16(&p, variant, out, ldo, gamma, beta, mean, rstd, G, eps, mode, rowbias, ldrb, res,
                                          ldr, Y != nullptr, stream);
 }
@@ -507,7 +532,7 @@ extern "C" int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred
   p.W = (const unsigned char*)W + (size_t)wcol0 * 2; p.ldw = ldw; p.Nout = Ncols; p.Npad = Npad;
   p.bias = nullptr; p.rowbias = nullptr; p.ldrb = 0;
   p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0; p.addend = addend; p.lda = ld_add; p.xcd = xcd_on();
+  p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0; p.addend = addend; p.lda = ld_add; p.xcd = xcd_on(); attach_ws(p);
   const int nsteps = (Kred / 64) * taps;
   p.ksplit = ksplit > 1 ? (ksplit < nsteps ? ksplit : nsteps) : 0;
   if (p.ksplit > 1) {
@@ -549,7 +574,7 @@ extern "C" int madiff_conv_dgrad_gn_bwd(const void* dY, int ldy, int M, int Kred
   p.W = W; p.ldw = ldw; p.Nout = Ncols; p.Npad = Ncols;
   p.bias = nullptr; p.rowbias = nullptr; p.ldrb = 0;
   p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 1; p.wtap = wtap; p.wcols = wtap; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on();
+  p.wt = 1; p.wtap = wtap; p.wcols = wtap; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p);
   return madiff_launch_conv_taps_gnb_bf16(&p, variant, Ypre, ldyp, gamma, beta, mean, rstd, G, dgamma, dbeta, dbias, drowbias,
                                           ldrb, stream);
 }

@@ -51,7 +51,25 @@ def pad32(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
+_SPLITK_WS: dict = {}          # device index -> (workspace, counters) registered with the library (kept alive here)
+SPLITK_WS_MB = int(os.environ.get("MADIFF_SPLITK_WS_MB", "64"))
+
+
+def _ensure_splitk_workspace() -> None:
+    """Register the all-taps kernel's reduction-split workspace for the current device, once (madiff_set_splitk_workspace).
+    Not under graph capture: the first eager call does it (every product path warms up eagerly before capturing)."""
+    dev = torch.cuda.current_device()
+    if dev in _SPLITK_WS or SPLITK_WS_MB <= 0 or torch.cuda.is_current_stream_capturing():
+        return
+    ws = torch.empty(SPLITK_WS_MB << 20, dtype=torch.uint8, device=f"cuda:{dev}")
+    cnt = torch.zeros(4096, dtype=torch.int32, device=f"cuda:{dev}")
+    lib.call("madiff_set_splitk_workspace", ws.data_ptr(), ws.numel(), cnt.data_ptr(), cnt.numel())
+    _SPLITK_WS[dev] = (ws, cnt)
+
+
 def _stream() -> int:
+    if torch.cuda.current_device() not in _SPLITK_WS:
+        _ensure_splitk_workspace()
     return torch.cuda.current_stream().cuda_stream
 
 

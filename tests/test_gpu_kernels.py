@@ -554,3 +554,38 @@ def test_conv_block_fused_matches_unfused(case, mode):
         assert torch.equal(outs[(True, False)][0], o1)             # dropping the y store changes nothing else
     finally:
         ops.FUSE_CONV_GN = old
+
+
+@pytest.mark.parametrize("case", ["n6_t6_c1024", "n13_t12_c512", "n5_t24_c256"])
+def test_all_taps_reduction_split_matches_unsplit(case):
+    """Small-batch layers: the all-taps kernel cuts the input channels into slices, partial tiles meet in the registered
+    workspace and the last workgroup finishes the tile (plain, fused GroupNorm forward, data gradient, fused GroupNorm
+    backward).  Against the same launches with the split switched off (MADIFF_CONV_SPLITK is read once per process, so the
+    reference here is torch): outputs to bf16 rounding, and the counters must be back at zero."""
+    import torch.nn.functional as F
+    from madiff_amd import modules as M, ops
+    ops.set_precision("bf16")
+    dev = _dev()
+    N, T, C = {"n6_t6_c1024": (6, 6, 1024), "n13_t12_c512": (13, 12, 512), "n5_t24_c256": (5, 24, 256)}[case]
+    x = _q(_rand(N, C, T, seed=1), "bf16").to(dev).requires_grad_(True)
+    w = _q(_rand(C, C, 5, seed=2, scale=1 / math.sqrt(C * 5)), "bf16").to(dev).requires_grad_(True)
+    b = _rand(C, seed=3, scale=0.1).to(dev).requires_grad_(True)
+    gamma = (_rand(C, seed=4) * 0.5 + 1).to(dev).requires_grad_(True)
+    beta = _rand(C, seed=5, scale=0.3).to(dev).requires_grad_(True)
+    temb = _rand(N, C, seed=6).to(dev).requires_grad_(True)
+    ref = F.mish(F.group_norm(F.conv1d(x, w, b, padding=2), 8, gamma, beta, eps=1e-5)) + temb[:, :, None]
+    gy = _q(_rand(*ref.shape, seed=7), "bf16").to(dev)
+    gref = torch.autograd.grad(ref, [x, w, b, gamma, beta, temb], gy)
+    ops._stream()                                              # registers the workspace
+    ws, cnt = ops._SPLITK_WS[torch.cuda.current_device()]
+    x2, w2, b2, g2, be2, t2 = [t.detach().clone().requires_grad_(True) for t in (x, w, b, gamma, beta, temb)]
+    out = ops.conv_block(M.to_cl(x2), w2, b2, g2, be2, ops.CONV5, T, 8, rowbias=t2)
+    o = M.from_cl(out, N, T, C)
+    assert rel_err(o.detach().cpu(), ref.detach().cpu()) < TOL["bf16"]
+    for a, r in zip(torch.autograd.grad(o, [x2, w2, b2, g2, be2, t2], gy), gref):
+        assert rel_err(a.cpu(), r.cpu()) < 3 * TOL["bf16"]
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0
+    # the split was really taken for this shape: few tiles, many chunks
+    import ctypes
+    assert ops.lib.exported("madiff_set_splitk_workspace")
