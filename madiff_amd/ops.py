@@ -1171,7 +1171,7 @@ def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, dr
                            0 if drb is None else drb.stride(0), variant, _stream())
 
     variant = _TUNE.get(sig)
-    if _TUNE.get(sig + ("use",)) is False:      # measured: data gradient + standalone GroupNorm backward is faster here
+    if _AUTOTUNE and _TUNE.get(sig + ("use",)) is False:      # measured: data gradient + standalone GroupNorm backward is faster here
         return None
     if variant is None and _AUTOTUNE and not torch.cuda.is_current_stream_capturing():
         scratch = torch.zeros(3, C, dtype=torch.float32, device=dy1.device)      # the timing launches accumulate here
@@ -1255,7 +1255,7 @@ def _conv_block_fused(x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w,
                            _stream())
 
     sig = ("convgn", M, cin, O, t_in, G, mode, need_y, x2 is not None)
-    if _TUNE.get(sig + ("use",)) is False:      # measured: convolution + standalone GroupNorm is faster for this shape
+    if _AUTOTUNE and _TUNE.get(sig + ("use",)) is False:      # measured: convolution + standalone GroupNorm is faster for this shape
         return None
     variant = _tuned_tile(sig, (1, 2), launch)
     if variant < 0:

@@ -79,6 +79,8 @@ def test_folded_loss_and_gradient_match_accumulation(prec, name, discrete, share
         if ("key_layer.bias" in k or "key_time_mlp" in k) and prec == "bf16":
             continue      # analytically zero (softmax shift invariance): in bf16 these gradients are rounding noise
         den = float(ref[k].abs().max())
+        if ref[k].numel() == 1:      # the attention gammas: near-cancelling sums, measured against the largest of them
+            den = max(float(v.abs().max()) for v in ref.values() if v.numel() == 1)
         if den < 1e-9:
             continue
         err = float((p.grad - ref[k]).abs().max()) / den
