@@ -22,6 +22,12 @@
 //   pipeline    step s = (chunk c, tap): counted s_waitcnt vmcnt -> one raw s_barrier -> issue W(s+2) (and A(c+1) at
 //               tap 0) -> 24 MFMAs per wave.  Two W stages and one A stage stay in flight across the barrier.
 //   epilogue    bias / row-bias / activation on 8-column vectors through a wave-private LDS tile, 16-byte stores.
+//   time-major  (tm = 1, launcher: SPT % 16 == 0, i.e. T = 6 on both tiles, T = 12 on the 192-row one) the tile's rows are
+//               ordered (t, sequence) instead of (sequence, t): tile row rho = t * SPT + s.  A 16-row A fragment then holds
+//               ONE time step of 16 sequences, so a tap whose shifted step leaves the sequence is outside it for the whole
+//               fragment and its 4 MFMAs are skipped (wave-uniform branch) instead of multiplying zeros: 6 of the 30
+//               (t, tap) pairs at T = 6.  The order exists only inside the tile: the A pieces are gathered with per-lane
+//               row addresses anyway, and the epilogues map rho back to the global row.
 #include "gemm_params.h"
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -69,7 +75,7 @@ struct GnEpi {
 // double-step reads or prefetches from plus the two in flight; needs an even number of channel chunks).
 template <int WM, bool WT, int D, bool GN, int VPL = 0, bool GNB = false>
 __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams p, int rows_used, int shift0, int shift_step,
-                                                                  GnEpi ge) {
+                                                                  GnEpi ge, int tm) {
   static_assert(!(GN && WT), "the GroupNorm epilogue belongs to the forward kernel");
   static_assert(!GNB || (WT && !GN), "the GroupNorm-backward epilogue belongs to the data-gradient kernel");
   constexpr int TAPS = 5;
@@ -89,6 +95,13 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   int bx = blockIdx.x, by = blockIdx.y;
   xcd_remap(bx, by, p.xcd);
   const int m0 = bx * rows_used, n0 = by * 128;
+  // time-major tiles: fragment i of this wave holds time step tf[i] of 16 sequences; loc() maps a tile row of that fragment
+  // to its row offset from m0
+  const int spt_t = rows_used / T;
+  int tf[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) tf[i] = tm ? (wm * 48 + i * 16) / spt_t : 0;
+  auto loc = [&](int i, int rho) { return tm ? (rho - tf[i] * spt_t) * T + tf[i] : rho; };
   const int cbase = p.cks > 1 ? (int)blockIdx.z * ((p.Cin >> 6) / p.cks) : 0;
 
   for (int i = tid; i < 512; i += NT) ((float*)(smem + (i >> 8) * A_BYTES + A_TILE))[i & 255] = 0.f;   // zero rows
@@ -101,7 +114,8 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   for (int j = 0; j < AP; j++) {
     const int row = (AP * wave + j) * 8 + (lane >> 3);
     const unsigned c16 = ((lane & 7) ^ (row & 7)) << 4;
-    const unsigned grow = row < rows_used ? min(m0 + row, p.M - 1) : m0;
+    const int lrow = tm ? (row % spt_t) * T + row / spt_t : row;
+    const unsigned grow = row < rows_used ? min(m0 + lrow, p.M - 1) : m0;
     a_off[0][j] = grow * (unsigned)(p.ldx * 2) + c16;
     a_off[1][j] = grow * (unsigned)(p.ldx2 * 2) + c16;
   }
@@ -145,18 +159,21 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
   const int fr = lane & 15, fq = lane >> 4;
   const int tq = fr >> 2, tp = fr & 3;
   int offA[TAPS][MI];
+  unsigned skip = 0;                       // bit (k * MI + i): (tap k, fragment i) lies wholly outside its sequences (tm only)
 #pragma unroll
   for (int i = 0; i < MI; i++) {
     const int ra = wm * 48 + i * 16 + fr;
-    const int t = ra % T;
+    const int t = tm ? tf[i] : ra % T;
 #pragma unroll
     for (int k = 0; k < TAPS; k++) {
       const int sh = shift0 + k * shift_step;
-      const int ts = t + sh, rs = ra + sh;
+      const int ts = t + sh, rs = ra + (tm ? sh * spt_t : sh);
       const int nat = rs * 128 + ((fq ^ (rs & 7)) << 4);
       offA[k][i] = (ra < rows_used && ts >= 0 && ts < T) ? nat : A_TILE + (nat & 255);
+      if (tm && (wm * 48 + i * 16 >= rows_used || tf[i] + sh < 0 || tf[i] + sh >= T)) skip |= 1u << (k * MI + i);
     }
   }
+  skip = __builtin_amdgcn_readfirstlane(skip);
   int offB[2];
   if constexpr (!WT) {
     const int rb = wn * 64 + fr;                          // + 16 j rows = + 2048 j bytes
@@ -194,12 +211,14 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       }
     }
   };
-  auto mma = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[NJ]) {
+  auto mma = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[NJ], const int tap) {
 #pragma unroll
-    for (int i = 0; i < MI; i++)
+    for (int i = 0; i < MI; i++) {
+      if (skip & (1u << (tap * MI + i))) continue;           // wave-uniform: the fragment is all zeros for this tap
 #pragma unroll
       for (int j = 0; j < NJ; j++)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
   };
 
   // ---- software pipeline.  Invariant at the top of step s = (c, tap): the kh = 0 fragments of step s are (being) loaded
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
         __builtin_amdgcn_sched_barrier(0);
         load_frags(a1, b1, As, Ws, offA[tap], 1);
         __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
+        mma(a0, b0, tap);
         __builtin_amdgcn_sched_barrier(0);
         if (!last) {
           const int fn = f + 1;
@@ -256,7 +275,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
           load_frags(a0, b0, An, Wbase + (fn % 5) * W_BYTES, offA[fn % TAPS], 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
+        mma(a1, b1, tap);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       __builtin_amdgcn_sched_barrier(0);
       load_frags(a1, b1, As, Ws, offA[tap], 1);
       __builtin_amdgcn_sched_barrier(0);
-      mma(a0, b0);
+      mma(a0, b0, tap);
       __builtin_amdgcn_sched_barrier(0);
       if (!last) {                                        // kh = 0 fragments of step s+1: legal before the next barrier
         const unsigned char* Wn = Wbase + nslot * W_BYTES;
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
         else load_frags(a0, b0, As, Wn, offA[tap + 1 < TAPS ? tap + 1 : 0], 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mma(a1, b1);
+      mma(a1, b1, tap);
       __builtin_amdgcn_sched_barrier(0);
       slot = nslot;
     }
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
 #pragma unroll
       for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) tile[(wm * 48 + i * 16 + fq * 4 + r) * LDG + col] = acc[i][j][r] + bv;
+        for (int r = 0; r < 4; r++) tile[loc(i, wm * 48 + i * 16 + fq * 4 + r) * LDG + col] = acc[i][j][r] + bv;
     }
     __syncthreads();
     bf16_t* Y = (bf16_t*)p.C;
@@ -528,7 +547,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
 #pragma unroll
       for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) tile[(wm * 48 + i * 16 + fq * 4 + r) * LDG + col] = acc[i][j][r];
+        for (int r = 0; r < 4; r++) tile[loc(i, wm * 48 + i * 16 + fq * 4 + r) * LDG + col] = acc[i][j][r];
     }
     __syncthreads();
     bf16_t* DY = (bf16_t*)p.C;
@@ -639,7 +658,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       const f32x4 v0 = *(const f32x4*)&stage[row * LDT + cv * 8];
       const f32x4 v1 = *(const f32x4*)&stage[row * LDT + cv * 8 + 4];
       const int lr = wm * 48 + i * 16 + row;
-      const int m = m0 + lr;
+      const int m = m0 + loc(i, lr);
       const int n = n0 + wn * WN + cv * 8;
       if (lr >= rows_used || m >= p.M || n >= p.Npad) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -690,6 +709,13 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
 // Reduction split of the all-taps kernel (p.cks, see gemm_params.h): only for layers whose output tiles leave most of the
 // chip idle; the slices must hold whole chunks (an even number of them for the two-steps-per-barrier variant) and the
 // partial tiles must fit the registered workspace.
+// Time-major tile order (see the header): needs fragments that hold one time step, i.e. SPT a multiple of 16.
+static int ct_time_major(int spt) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MADIFF_CONV_TM"); on = e ? atoi(e) : 1; }
+  return on && spt >= 16 && spt % 16 == 0;
+}
+
 static int ct_pick_cks(const GemmFwdParams& p, long tiles, int variant) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("MADIFF_CONV_SPLITK"); on = e ? atoi(e) : 1; }
@@ -735,7 +761,7 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_bf1
   p.cks = ct_pick_cks(p, (long)grid.x * grid.y, variant);
   grid.z = p.cks;
   GnEpi ge = {};
-#define CT_LAUNCH(WM_, WT_, D_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, WT_, D_, false>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, shift0, shift_step, ge)
+#define CT_LAUNCH(WM_, WT_, D_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, WT_, D_, false>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, shift0, shift_step, ge, ct_time_major(spt))
   if (variant == 2) {          // 192 rows, 5-deep W ring, one barrier per two (chunk, tap) steps
     if (p.wt) CT_LAUNCH(4, true, 5); else CT_LAUNCH(4, false, 5);
   } else if (variant == 0) {   // 192 rows: one 8-wave workgroup per CU, 4-deep W ring
@@ -788,7 +814,7 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_
   // epilogue geometry: VPL = ceil(T / 4) row iterations per lane, 8 / VPL sequences per wave must cover the tile's share
   const int vpl = (T + 3) / 4, nw = variant == 1 ? 4 : 8;
   if ((spt + nw - 1) / nw > 8 / vpl) return 1;
-#define CT_GN(WM_, D_, V_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, false, D_, true, V_>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, -2, 1, ge)
+#define CT_GN(WM_, D_, V_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, false, D_, true, V_>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, -2, 1, ge, ct_time_major(spt))
 #define CT_GN_VPL(WM_, D_)                                    \
   switch (vpl) {                                              \
     case 2: CT_GN(WM_, D_, 2); break;                         \
@@ -846,7 +872,7 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gnb
   grid.z = p.cks;
   const int vpl = (T + 3) / 4, nw = variant == 1 ? 4 : 8;
   if ((spt + nw - 1) / nw > 8 / vpl) return 1;
-#define CT_GNB(WM_, D_, V_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, true, D_, false, V_, true>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, 2, -1, ge)
+#define CT_GNB(WM_, D_, V_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, true, D_, false, V_, true>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, 2, -1, ge, ct_time_major(spt))
 #define CT_GNB_VPL(WM_, D_)                                   \
   switch (vpl) {                                              \
     case 2: CT_GNB(WM_, D_, 2); break;                        \

@@ -756,9 +756,18 @@ __global__ __launch_bounds__(256, (BO >= 128 ? 1 : 2)) void gemm_wgrad_taps_bf16
 // (2 x 21 MB per layer at the ~1.3 TB/s chip-wide atomic rate, issued by all workgroups at the same moment at the end:
 // a ~30 us tail on an 85 us kernel).  Here 256 workgroups of 8 waves fill the chip without a split, and the tile is
 // added to the live gradient by plain read-modify-write 64-byte row segments (splits == 1) -- no atomics at all.
+//
+// TM (time-major K order, T = 6 only): the order of the reduction rows inside a K-step is free, so the 192 rows = 32
+// sequences x 6 steps are staged as (t, sequence): LDS row = 32 t + s, i.e. 32-row chunk t holds time step t of all 32
+// sequences.  Then dW[:, k, :] += sum_t Y_t^T X_(t+k-2) over WHOLE chunks: the X fragment of (chunk t, tap k) is chunk
+// t+k-2 unshifted, the pairs whose t+k-2 leaves [0, 6) are not computed at all (24 of 30 remain), and each X chunk is
+// read from LDS once per K-step for all the taps it serves (8 fragment sets per wave and K-step instead of 18).  Group 0
+// takes t = 0, 1, 2 and X chunks 0..4; group 1 the mirror image (t = 5, 4, 3, chunks 5..1), so both run the same code
+// with accumulator a holding tap a (group 0) or tap 4 - a (group 1, swapped back before the exchange).
 // ------------------------------------------------------------------------------------------------
-template <int TAPS, int NQ, int D>
+template <int TAPS, int NQ, int D, bool TM = false>
 __global__ __launch_bounds__(512) void gemm_wgrad_taps8_bf16_kernel(GemmWgradParams p) {
+  static_assert(!TM || (TAPS == 5 && NQ == 3), "time-major K order: T = 6, k = 5");
   constexpr int BO = 64, BC = 64, KG = 2;
   constexpr int KR = 32 * NQ * KG;
   constexpr int MI = BO / 32, NJ = BC / 32;
@@ -790,19 +799,21 @@ __global__ __launch_bounds__(512) void gemm_wgrad_taps8_bf16_kernel(GemmWgradPar
   int ldx = p.ldx, cx = c0, cmax = p.Csplit;
   if (c0 >= p.Csplit) { xsrc = (const unsigned char*)p.X2; ldx = p.ldx2; cx = c0 - p.Csplit; cmax = p.Cin - p.Csplit; }
 
-  int yrow[YP], xrow[XP];
+  int yrow[YP], xrow[XP];                  // row offset of the piece's lane from the first row of the K-step (global side)
   const unsigned char* ysrc0[YP];
   const unsigned char* xsrc0[XP];
 #pragma unroll
   for (int j = 0; j < YP; j++) {
-    yrow[j] = (YP * wave + j) * YRP + lane / YCH;
-    int ch = (lane % YCH) ^ tr_swz<BO>(yrow[j]);
+    const int lr = (YP * wave + j) * YRP + lane / YCH;                   // LDS row
+    int ch = (lane % YCH) ^ tr_swz<BO>(lr);
+    yrow[j] = TM ? (lr & 31) * T + (lr >> 5) : lr;
     ysrc0[j] = n0 + ch * 8 < p.Ycols ? (const unsigned char*)p.dY + ((size_t)yrow[j] * p.ldy + n0 + ch * 8) * 2 : nullptr;
   }
 #pragma unroll
   for (int j = 0; j < XP; j++) {
-    xrow[j] = (XP * wave + j) * 8 + (lane >> 3);
-    int ch = (lane & 7) ^ tr_swz<BC>(xrow[j]);
+    const int lr = (XP * wave + j) * 8 + (lane >> 3);
+    int ch = (lane & 7) ^ tr_swz<BC>(lr);
+    xrow[j] = TM ? (lr & 31) * T + (lr >> 5) : lr;
     xsrc0[j] = cx + ch * 8 < cmax ? xsrc + ((size_t)xrow[j] * ldx + cx + ch * 8) * 2 : nullptr;
   }
   const unsigned char* zero = g_zero_page + (lane & 15) * 16;
@@ -833,7 +844,8 @@ __global__ __launch_bounds__(512) void gemm_wgrad_taps8_bf16_kernel(GemmWgradPar
     unsigned yo[2], xo[2][TAPS];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const int r = 32 * (g * NQ + q) + 8 * fq + tq + 4 * h;    // this wave group's rows of the K-step
+      const int cq = TM ? (g ? 2 * NQ - 1 - q : q) : g * NQ + q;   // TM: chunk = time step, group 1 mirrored
+      const int r = 32 * cq + 8 * fq + tq + 4 * h;              // this wave group's rows of the K-step
       yo[h] = r * (BO * 2) + ((((YCH / 2) * wn + (tp >> 1)) ^ tr_swz<BO>(r)) << 4) + o8;
       const int t = r % T;
 #pragma unroll
@@ -848,6 +860,18 @@ __global__ __launch_bounds__(512) void gemm_wgrad_taps8_bf16_kernel(GemmWgradPar
     yoff[q] = yo[0] | (yo[1] << 16);
 #pragma unroll
     for (int k = 0; k < TAPS; k++) xoff[q][k] = xo[0][k] | (xo[1][k] << 16);
+  }
+  if constexpr (TM) {                      // xoff[0][u']: X chunk u = u' (group 0) or 5 - u' (group 1), unshifted
+#pragma unroll
+    for (int uu = 0; uu < TAPS; uu++) {
+      unsigned xo[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int rs = 32 * (g ? 2 * NQ - 1 - uu : uu) + 8 * fq + tq + 4 * h;
+        xo[h] = rs * (BC * 2) + (((4 * wc + (tp >> 1)) ^ tr_swz<BC>(rs)) << 4) + o8;
+      }
+      xoff[0][uu] = xo[0] | (xo[1] << 16);
+    }
   }
 
   f32x4 acc[TAPS][MI][NJ];
@@ -899,6 +923,33 @@ __global__ __launch_bounds__(512) void gemm_wgrad_taps8_bf16_kernel(GemmWgradPar
     // fragment pipeline inside a stage, two positions deep: while the 4 MFMAs of position t = (chunk q, tap k) run, the X
     // fragments of position t+2 are being read (three register sets); 4 MFMAs = 64 cycles alone do not cover one LDS
     // round trip under load.  The dY fragments of chunk q+1 are read at the same distance.
+    if constexpr (TM) {
+      // all three dY chunks of the group stay in registers; X chunks stream through a 3-deep register ring
+      bf16x8 ya[NQ][MI], xb[3][NJ];
+      load_a(ya[0], 0);
+      load_b(xb[0], 0, 0);
+      load_a(ya[1], 1);
+      load_a(ya[2], 2);
+      load_b(xb[1], 0, 1);
+#pragma unroll
+      for (int uu = 0; uu < TAPS; uu++) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (uu + 2 < TAPS) load_b(xb[(uu + 2) % 3], 0, uu + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int a = uu - q + 2;                       // accumulator (= tap for group 0, 4 - tap for group 1)
+          if (a < 0 || a >= TAPS) continue;
+#pragma unroll
+          for (int i = 0; i < MI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+              acc[a][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya[q][i], xb[uu % 3][j], acc[a][i][j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      continue;
+    }
     bf16x8 a[2][MI], b[3][NJ];
     load_a(a[0], 0);
     load_b(b[0], 0, 0);
@@ -925,6 +976,16 @@ __global__ __launch_bounds__(512) void gemm_wgrad_taps8_bf16_kernel(GemmWgradPar
   // ---- combine the two groups' partial tiles through LDS.  The (tap, i) slices of a round are split between the groups;
   // each group hands the other one the slices it does not own, then adds what it received and updates global memory.
   // Rounds (taps [0, TSPLIT) then [TSPLIT, TAPS)) keep the exchange inside the staging memory.
+  if constexpr (TM) {
+    if (g) {                               // group 1 accumulated tap 4 - a in accumulator a
+#pragma unroll
+      for (int k = 0; k < TAPS / 2; k++)
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+          for (int j = 0; j < NJ; j++) { const f32x4 tmp = acc[k][i][j]; acc[k][i][j] = acc[TAPS - 1 - k][i][j]; acc[TAPS - 1 - k][i][j] = tmp; }
+    }
+  }
   constexpr int TSPLIT = TAPS;
   static_assert(((TSPLIT * MI + 1) / 2) * 2 * NJ * 4 * 256 * 4 <= D * BUF_BYTES, "the partial-tile exchange reuses the staging memory");
   float* red = (float*)smem;
@@ -983,6 +1044,9 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_wgrad_ta
                                                                                         hipStream_t stream) {
   const GemmWgradParams& p = *(const GemmWgradParams*)params;
   if (p.taps != 5 || (nq != 1 && nq != 3)) return -1;
+  static int tm_on = -1;
+  if (tm_on < 0) { const char* e = getenv("MADIFF_WGRAD_TM"); tm_on = e ? atoi(e) : 1; }
+  const bool tm = tm_on && p.rm.T_out == 6 && p.rm.pad == 2;     // time-major K order (8-wave form only)
   dim3 grid(gx, gy, gz);
 #define MADIFF_WT(V, BO_, D_)                                                                                           \
   case V:                                                                                                               \
@@ -991,7 +1055,8 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_wgrad_ta
     break;
 #define MADIFF_WT8(V, D_, D1_)                                                                                          \
   case V:                                                                                                               \
-    if (nq == 3) hipLaunchKernelGGL((gemm_wgrad_taps8_bf16_kernel<5, 3, D_>), grid, dim3(512), 0, stream, p);           \
+    if (nq == 3 && tm) hipLaunchKernelGGL((gemm_wgrad_taps8_bf16_kernel<5, 3, D_, true>), grid, dim3(512), 0, stream, p); \
+    else if (nq == 3) hipLaunchKernelGGL((gemm_wgrad_taps8_bf16_kernel<5, 3, D_>), grid, dim3(512), 0, stream, p);      \
     else hipLaunchKernelGGL((gemm_wgrad_taps8_bf16_kernel<5, 1, D1_>), grid, dim3(512), 0, stream, p);                  \
     break;
   switch (variant) {

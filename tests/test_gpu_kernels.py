@@ -85,14 +85,17 @@ def test_conv_gemm_fwd_bwd(prec, case):
         assert rel_err(a.cpu(), b.cpu()) < TOL[prec] * (3 if prec == "bf16" else 1), name
 
 
-@pytest.mark.parametrize("case", ["conv5", "conv5_t24", "conv5_t8", "down", "up", "conv1_ragged"])
+@pytest.mark.parametrize("case", ["conv5", "conv5_t6_tiles", "conv5_t12_tiles", "conv5_t24", "conv5_t8", "down", "up", "conv1_ragged"])
 def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
     """Every output tile of the LDS-DMA kernel gives bit-identical results (forward), and the data gradient computed
     straight from the forward weight layout (transposing LDS reads) matches autograd, for each of its tiles."""
     from madiff_amd import lib, modules as M, ops
     ops.set_precision("bf16")
     dev = _dev()
-    cfgs = {"conv5": (9, 6, 192, 128, ops.CONV5), "conv5_t24": (7, 24, 128, 192, ops.CONV5),
+    # (conv5_t6_tiles / conv5_t12_tiles: several output tiles and K-steps, the last one partly filled, at the sequence
+    # lengths where the all-taps kernels order their rows time-major and skip the taps that leave the sequence)
+    cfgs = {"conv5": (9, 6, 192, 128, ops.CONV5), "conv5_t6_tiles": (75, 6, 128, 128, ops.CONV5),
+            "conv5_t12_tiles": (37, 12, 64, 128, ops.CONV5), "conv5_t24": (7, 24, 128, 192, ops.CONV5),
             "conv5_t8": (13, 8, 64, 64, ops.CONV5), "down": (5, 12, 64, 256, ops.DOWN), "up": (7, 6, 128, 128, ops.UP),
             "conv1_ragged": (11, 7, 320, 192, ops.CONV1)}
     N, T, Cin, Co, spec = cfgs[case]
@@ -112,7 +115,7 @@ def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
     # (all-taps k5 kernel, conv_taps_bf16.hip: channel-chunk-major order) cover stride-1 k5 layers only, agree with each
     # other bit for bit and with the others to bf16 rounding.
     FIRST_TAPS = 14
-    taps_case = case in ("conv5", "conv5_t24", "conv5_t8")
+    taps_case = case.startswith("conv5")
     outs = {}
     for tile in range(lib.tile_count()):
         y = torch.full((N * T2, Co), float("nan"), dtype=torch.bfloat16, device=dev)
@@ -156,7 +159,7 @@ def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
                 rc = lib.call_rc("madiff_gemm_wgrad", lib.BF16, gycl.data_ptr(), gycl.stride(0), gycl.shape[1],
                                  xcl.data_ptr(), xcl.stride(0), None, 0, Cin, N * T2, Cin, k, T2, T, spec.stride, spec.pad,
                                  spec.tr, dW.data_ptr(), dW.stride(0), Co, accumulate, tile, splits, st)
-                assert rc == (0 if (tile < 4 or case in ("conv5", "conv5_t24", "conv5_t8")) else 1), (tile, rc)
+                assert rc == (0 if (tile < 4 or taps_case) else 1), (tile, rc)
                 if rc:
                     continue
                 got = dW.view(Co, k, Cin) - (1.0 if accumulate else 0.0)
