@@ -922,6 +922,9 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
 
 WGRAD_SIDE_STREAM = os.environ.get("MADIFF_WGRAD_SIDE_STREAM", "1") != "0"
 FUSE_BIAS_WGRAD = os.environ.get("MADIFF_FUSE_BIAS_WGRAD", "1") != "0"
+# parameter-gradient launches go round-robin over this many auxiliary streams (parallel branches of the captured step)
+WGRAD_STREAMS = int(os.environ.get("MADIFF_WGRAD_STREAMS", "2"))
+_WGRAD_RR = 0
 
 
 def _param_grads_side(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
@@ -936,7 +939,9 @@ def _param_grads_side(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
             and (bias_mode != "colsum" or all(_sink_view(b) is not None for b in biases))):
         return _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw)
     cur = torch.cuda.current_stream()
-    side = aux_stream(dy.device, "wgrad")
+    global _WGRAD_RR
+    side = aux_stream(dy.device, "wgrad" if WGRAD_STREAMS <= 1 else "wgrad%d" % (_WGRAD_RR % WGRAD_STREAMS))
+    _WGRAD_RR += 1
     wait_stream(side, cur)
     sink.deferred = []
     try:
