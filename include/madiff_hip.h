@@ -118,6 +118,17 @@ int madiff_conv_dgrad_gn_bwd(const void* dY, int ldy, int M, int Kred, int T, co
                              const float* rstd, int G, void* dX, int ldx, float* dgamma, float* dbeta, float* dbias,
                              float* drowbias, int ldrb, int variant, madiff_stream_t stream);
 
+/* The same launch for two CONSECUTIVE ResidualTemporalBlocks (reference diffuser/models/temporal.py:197-200, twice: the
+   first block's output feeds the second one only): B = the second block's blocks[0] convolution, A = the first block's
+   blocks[1] (GroupNorm + Mish, then the residual add).  dh = dY (*) W_B + addend is the gradient of the first block's
+   output (addend = the second block's residual-branch gradient, may be NULL); it is stored to dH [M, ldh] because the first
+   block's residual branch needs it, and taken through A's GroupNorm + Mish backward into dX in the same epilogue.  Replaces
+   madiff_gemm_dgrad_wt_add + madiff_gn_mish_bwd (one launch less per block pair).  Status as madiff_conv_dgrad_gn_bwd. */
+int madiff_conv_dgrad_gn_bwd_chain(const void* dY, int ldy, int M, int Kred, int T, const void* W, int ldw, int wtap, int Ncols,
+                                   const void* Ypre, int ldyp, const float* gamma, const float* beta, const float* mean,
+                                   const float* rstd, int G, void* dX, int ldx, float* dgamma, float* dbeta, float* dbias,
+                                   const void* addend, int ld_add, void* dH, int ldh, int variant, madiff_stream_t stream);
+
 /* Weight gradient of the above: dW[o, tap*Cin + c] (+)= sum_m dY[m, o] * X[src(m, tap), c]  (fp32 output).
  * Replaces the wgrad half of autograd for the same modules.  accumulate != 0 adds into dW (a live gradient buffer
  * kept in this GEMM layout by the flat optimizer), 0 overwrites.  tile: variant of the gfx950 LDS-DMA kernel, < 0 =

@@ -69,15 +69,20 @@ struct GnEpi {
   const float* bmean; const float* brstd;     // its statistics [n_seq * G]
   float* dgamma; float* dbeta; float* dbias;  // [C], accumulated atomically (dbias = the preceding conv's bias gradient, may be null)
   float* drowb; int lddrb;                    // d rowbias [n_seq, lddrb] = sum_t dh (mode 1: the time-embedding term), or null
+  // chained form (CH): dh = dgrad(conv) + gadd is ALSO a gradient somebody else needs (the preceding block's residual
+  // branch), so it is stored to dhout as well, and gadd (this block's own residual-branch gradient) joins it first
+  const bf16_t* gadd; int ldga;               // addend [(n,t), ldga] or null
+  bf16_t* dhout; int lddh;                    // dh [(n,t), lddh]
 };
 
 // D = 3 / 4: one barrier per (chunk, tap) step.  D = 5: one barrier per TWO steps (the ring then holds the three stages a
 // double-step reads or prefetches from plus the two in flight; needs an even number of channel chunks).
-template <int WM, bool WT, int D, bool GN, int VPL = 0, bool GNB = false>
+template <int WM, bool WT, int D, bool GN, int VPL = 0, bool GNB = false, bool CH = false>
 __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams p, int rows_used, int shift0, int shift_step,
                                                                   GnEpi ge, int tm) {
   static_assert(!(GN && WT), "the GroupNorm epilogue belongs to the forward kernel");
   static_assert(!GNB || (WT && !GN), "the GroupNorm-backward epilogue belongs to the data-gradient kernel");
+  static_assert(!CH || GNB, "the chained form is a variant of the GroupNorm-backward epilogue");
   constexpr int TAPS = 5;
   static_assert(D == 3 || D == 4 || D == 5, "W ring depth");
   constexpr int BM = 48 * WM, NW = 2 * WM, NT = NW * 64;
@@ -524,6 +529,7 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
     const int spt = rows_used / T, n_seq = p.M / T;
     const int g = c0 / Cg;
     bf16x8 yv[SEQ][VPL];
+    bf16x8 adv[CH ? SEQ : 1][CH ? VPL : 1];
     float mean[SEQ], rstd[SEQ];
     float gmv[8], btv[8], a_dg[8], a_db[8], a_dbias[8];
 #pragma unroll
@@ -538,6 +544,9 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       for (int i = 0; i < VPL; i++) {
         const int r = r0 + 4 * i;
         if (live && r < T) yv[sl][i] = *(const bf16x8*)(ge.by + ((size_t)n * T + r) * ge.ldby + c0);
+        if constexpr (CH) {
+          if (live && r < T && ge.gadd) adv[sl][i] = *(const bf16x8*)(ge.gadd + ((size_t)n * T + r) * ge.ldga + c0);
+        }
       }
     }
     __syncthreads();                         // every wave is done with the operand tiles; no DMA is outstanding
@@ -565,7 +574,17 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
         if (live && r < T) {
           const f32x4 a = *(const f32x4*)&tile[(sq * T + r) * LDG + cv * 8];
           const f32x4 b = *(const f32x4*)&tile[(sq * T + r) * LDG + cv * 8 + 4];
-          const float go[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+          float go[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+          if constexpr (CH) {
+            if (ge.gadd) {
+#pragma unroll
+              for (int e = 0; e < 8; e++) go[e] += (float)adv[sl][i][e];
+            }
+            bf16x8 oh;
+#pragma unroll
+            for (int e = 0; e < 8; e++) oh[e] = (bf16_t)go[e];
+            *(bf16x8*)(ge.dhout + ((size_t)n * T + r) * ge.lddh + c0) = oh;
+          }
 #pragma unroll
           for (int e = 0; e < 8; e++) {
             const float x = ((float)yv[sl][i][e] - mean[sl]) * rstd[sl];
@@ -838,7 +857,8 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_
 // (p.C / p.ldc receive dy of the preceding block instead of dh).  Returns 1 when the layer is not covered.
 extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gnb_bf16(
     const void* params, int variant, const void* ypre, int ldyp, const float* gamma, const float* beta, const float* mean,
-    const float* rstd, int G, float* dgamma, float* dbeta, float* dbias, float* drowbias, int ldrb, hipStream_t stream) {
+    const float* rstd, int G, float* dgamma, float* dbeta, float* dbias, float* drowbias, int ldrb, const void* gadd, int ldga,
+    void* dhout, int lddh, hipStream_t stream) {
   GemmFwdParams p = *(const GemmFwdParams*)params;
   const int BM = variant == 1 ? 96 : 192;
   const int T = p.rm.T_out;
@@ -857,6 +877,9 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gnb
     return -1;
   if (((size_t)ypre % 16) || (ldyp % 8) || ((size_t)p.C % 16) || (p.ldc % 8) || (drowbias && (((size_t)drowbias % 16) || ldrb % 4)))
     return 1;
+  if (gadd && !dhout) return -1;                               // the addend only exists in the chained form
+  if (dhout && (lddh < p.Nout || (gadd && ldga < p.Nout))) return -1;
+  if (dhout && (((size_t)dhout % 16) || lddh % 8 || (gadd && (((size_t)gadd % 16) || ldga % 8)))) return 1;
   {
     const size_t wext = (size_t)p.Cin * p.ldw * 2;
     if ((size_t)p.M * (size_t)p.ldx * 2 >= (1ull << 31) || wext >= (1ull << 31)) return 1;
@@ -865,6 +888,7 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gnb
   ge.gamma = gamma; ge.beta = beta; ge.G = G; ge.gv_log2 = gl;
   ge.by = (const bf16_t*)ypre; ge.ldby = ldyp; ge.bmean = mean; ge.brstd = rstd;
   ge.dgamma = dgamma; ge.dbeta = dbeta; ge.dbias = dbias; ge.drowb = drowbias; ge.lddrb = ldrb;
+  ge.gadd = (const bf16_t*)gadd; ge.ldga = ldga; ge.dhout = (bf16_t*)dhout; ge.lddh = lddh;
   const int spt = BM / T, rows_used = spt * T;
   const int n_seq = p.M / T;
   dim3 grid((n_seq + spt - 1) / spt, p.Nout / 128);
@@ -872,7 +896,11 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gnb
   grid.z = p.cks;
   const int vpl = (T + 3) / 4, nw = variant == 1 ? 4 : 8;
   if ((spt + nw - 1) / nw > 8 / vpl) return 1;
-#define CT_GNB(WM_, D_, V_) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, true, D_, false, V_, true>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, 2, -1, ge, ct_time_major(spt))
+#define CT_GNB(WM_, D_, V_)                                                                                              \
+  do {                                                                                                                  \
+    if (dhout) hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, true, D_, false, V_, true, true>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, 2, -1, ge, ct_time_major(spt)); \
+    else hipLaunchKernelGGL((conv_taps_bf16_kernel<WM_, true, D_, false, V_, true>), grid, dim3(WM_ * 128), 0, stream, p, rows_used, 2, -1, ge, ct_time_major(spt)); \
+  } while (0)
 #define CT_GNB_VPL(WM_, D_)                                   \
   switch (vpl) {                                              \
     case 2: CT_GNB(WM_, D_, 2); break;                        \

@@ -548,7 +548,8 @@ extern "C" int madiff_colsum(int dtype, const void* x, int ld, float* out, long 
 extern "C" int madiff_colsum_scatter(int dtype, const void* x, int ld, float* const* table, long M, int C, hipStream_t stream);
 extern "C" int madiff_launch_conv_taps_gnb_bf16(const void* params, int variant, const void* ypre, int ldyp, const float* gamma,
                                                 const float* beta, const float* mean, const float* rstd, int G, float* dgamma,
-                                                float* dbeta, float* dbias, float* drowbias, int ldrb, hipStream_t stream);
+                                                float* dbeta, float* dbias, float* drowbias, int ldrb, const void* gadd,
+                                                int ldga, void* dhout, int lddh, hipStream_t stream);
 
 // Backward of "Conv1dBlock A -> k5 convolution B" in ONE launch (bf16 build): the data gradient of B (as
 // madiff_gemm_dgrad_wt: dh = dY (*) W_B, straight from B's forward weight matrix) followed, in the kernel's epilogue, by the
@@ -558,11 +559,42 @@ extern "C" int madiff_launch_conv_taps_gnb_bf16(const void* params, int variant,
 // drowbias ([M/T, ldrb] = sum_t dh, the gradient of the per-sequence term added after A: temporal.py:197) may be NULL.
 // In ResidualTemporalBlock: A = blocks[0], B = blocks[1]'s convolution.  variant: 1 = 96-row tile, 2 = 192-row tile.
 // Returns 1 when the layer is not covered (caller: madiff_gemm_dgrad_wt + madiff_gn_mish_bwd).
+static int dgrad_gn_bwd_impl(const void* dY, int ldy, int M, int Kred, int T, const void* W, int ldw, int wtap, int Ncols,
+                             const void* Ypre, int ldyp, const float* gamma, const float* beta, const float* mean,
+                             const float* rstd, int G, void* dX, int ldx, float* dgamma, float* dbeta, float* dbias,
+                             float* drowbias, int ldrb, const void* addend, int ld_add, void* dH, int ldh, int variant,
+                             hipStream_t stream);
+
 extern "C" int madiff_conv_dgrad_gn_bwd(const void* dY, int ldy, int M, int Kred, int T, const void* W, int ldw, int wtap,
                                         int Ncols, const void* Ypre, int ldyp, const float* gamma, const float* beta,
                                         const float* mean, const float* rstd, int G, void* dX, int ldx, float* dgamma,
                                         float* dbeta, float* dbias, float* drowbias, int ldrb, int variant,
                                         hipStream_t stream) {
+  return dgrad_gn_bwd_impl(dY, ldy, M, Kred, T, W, ldw, wtap, Ncols, Ypre, ldyp, gamma, beta, mean, rstd, G, dX, ldx, dgamma,
+                           dbeta, dbias, drowbias, ldrb, nullptr, 0, nullptr, 0, variant, stream);
+}
+
+// The same launch where dh is ALSO somebody's gradient: two consecutive ResidualTemporalBlocks (temporal.py:197-200 twice:
+// the first block's output feeds the second one only).  B = the second block's blocks[0] convolution, A = the FIRST block's
+// blocks[1] (GroupNorm + Mish + residual add).  dh = dY (*) W_B + addend (addend = the second block's residual-branch
+// gradient, may be NULL) is the gradient of the first block's output: it is stored to dH (the first block's residual
+// branch consumes it) and, in the same epilogue, taken through A's GroupNorm + Mish backward into dX.  Replaces
+// madiff_gemm_dgrad_wt_add + madiff_gn_mish_bwd.  Status as madiff_conv_dgrad_gn_bwd.
+extern "C" int madiff_conv_dgrad_gn_bwd_chain(const void* dY, int ldy, int M, int Kred, int T, const void* W, int ldw, int wtap,
+                                              int Ncols, const void* Ypre, int ldyp, const float* gamma, const float* beta,
+                                              const float* mean, const float* rstd, int G, void* dX, int ldx, float* dgamma,
+                                              float* dbeta, float* dbias, const void* addend, int ld_add, void* dH, int ldh,
+                                              int variant, hipStream_t stream) {
+  if (!dH) return -1;
+  return dgrad_gn_bwd_impl(dY, ldy, M, Kred, T, W, ldw, wtap, Ncols, Ypre, ldyp, gamma, beta, mean, rstd, G, dX, ldx, dgamma,
+                           dbeta, dbias, nullptr, 0, addend, ld_add, dH, ldh, variant, stream);
+}
+
+static int dgrad_gn_bwd_impl(const void* dY, int ldy, int M, int Kred, int T, const void* W, int ldw, int wtap, int Ncols,
+                             const void* Ypre, int ldyp, const float* gamma, const float* beta, const float* mean,
+                             const float* rstd, int G, void* dX, int ldx, float* dgamma, float* dbeta, float* dbias,
+                             float* drowbias, int ldrb, const void* addend, int ld_add, void* dH, int ldh, int variant,
+                             hipStream_t stream) {
   if (M <= 0 || Ncols <= 0) return 0;
   if (!use_dma_kernel() || Kred % 64 || wtap % 8 || ldw % 8) return 1;
   if (T <= 0 || M % T || ldy < Kred || ldy % 8 || ldx < Ncols || Ncols > wtap || ldw < 5 * wtap || variant < 1 || variant > 2)
@@ -576,7 +608,7 @@ extern "C" int madiff_conv_dgrad_gn_bwd(const void* dY, int ldy, int M, int Kred
   p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
   p.wt = 1; p.wtap = wtap; p.wcols = wtap; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p);
   return madiff_launch_conv_taps_gnb_bf16(&p, variant, Ypre, ldyp, gamma, beta, mean, rstd, G, dgamma, dbeta, dbias, drowbias,
-                                          ldrb, stream);
+                                          ldrb, addend, ld_add, dH, ldh, stream);
 }
 
 static int wgrad_impl(int dtype, const void* dY, int ldy, int Ycols, const void* X, int ldx, const void* X2, int ldx2,

@@ -36,6 +36,8 @@ _SIGS = {
     "madiff_gemm_dgrad_wt_add": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],
     "madiff_conv_dgrad_gn_bwd": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp,
                                  _vp, _i, _i, _vp],
+    "madiff_conv_dgrad_gn_bwd_chain": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp,
+                                       _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
     "madiff_gemm_wgrad": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i,
                           _vp],
     "madiff_gemm_wgrad_bias": [_i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i,

@@ -603,6 +603,53 @@ def test_dgrad_gn_bwd_fused_matches_autograd(case, variant):
     assert rel_err(drb.cpu(), temb.grad.cpu()) < tol
 
 
+@pytest.mark.parametrize("case", ["t6_c128", "t6_c256_tiles", "t12_c512", "t24_c128", "t7_c256_ragged"])
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_dgrad_gn_bwd_chain_matches_autograd(case, variant, with_addend):
+    """madiff_conv_dgrad_gn_bwd_chain: the form for two consecutive ResidualTemporalBlocks, where dh = dgrad + addend is
+    itself a gradient that has to reach memory (dH) besides going through the preceding block's GroupNorm + Mish
+    backward.  Reference: torch autograd of  <dz, conv5(o)> + <add, o>,  o = mish(GN(y0))."""
+    from madiff_amd import lib, modules as M, ops
+    ops.set_precision("bf16")
+    dev = _dev()
+    N, T, C, Co = {"t6_c128": (37, 6, 128, 128), "t6_c256_tiles": (75, 6, 256, 128), "t12_c512": (19, 12, 512, 256),
+                   "t24_c128": (9, 24, 128, 128), "t7_c256_ragged": (41, 7, 256, 128)}[case]
+    G = 8
+    y0 = _q(_rand(N, C, T, seed=1), "bf16").to(dev).requires_grad_(True)
+    wB = _q(_rand(Co, C, 5, seed=2, scale=1 / math.sqrt(C * 5)), "bf16").to(dev)
+    gamma = (1 + 0.3 * _rand(C, seed=4)).to(dev).requires_grad_(True)
+    beta = (0.2 * _rand(C, seed=5)).to(dev).requires_grad_(True)
+    dz = _q(_rand(N, Co, T, seed=7), "bf16").to(dev)
+    add = _q(_rand(N, C, T, seed=8), "bf16").to(dev)
+    o = F.mish(F.group_norm(y0, G, gamma, beta, eps=1e-5))
+    o.retain_grad()
+    loss = (F.conv1d(o, wB, None, padding=2) * dz).sum()
+    if with_addend:
+        loss = loss + (o * add).sum()
+    loss.backward()
+    yg = y0.detach().view(N, G, (C // G) * T)
+    mean = yg.mean(dim=2).reshape(-1).contiguous()
+    rstd = torch.rsqrt(yg.var(dim=2, unbiased=False) + 1e-5).reshape(-1).contiguous()
+    Wf = ops._packed([wB], ops.CONV5, False)
+    dzcl, y0cl, addcl = M.to_cl(dz), M.to_cl(y0.detach()), M.to_cl(add)
+    dX = torch.full((N * T, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    dH = torch.full((N * T, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    dgamma, dbeta, dbias = (torch.full((C,), 0.5, device=dev) for _ in range(3))
+    rc = lib.call_rc("madiff_conv_dgrad_gn_bwd_chain", dzcl.data_ptr(), dzcl.stride(0), N * T, Co, T, Wf.data_ptr(),
+                     Wf.stride(0), C, C, y0cl.data_ptr(), y0cl.stride(0), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                     rstd.data_ptr(), G, dX.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(), dbias.data_ptr(),
+                     addcl.data_ptr() if with_addend else None, C, dH.data_ptr(), C, variant,
+                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+    tol = 3 * TOL["bf16"]
+    assert rel_err(M.from_cl(dH, N, T, C).float().cpu(), o.grad.cpu()) < tol
+    assert rel_err(M.from_cl(dX, N, T, C).float().cpu(), y0.grad.cpu()) < tol
+    assert rel_err((dgamma - 0.5).cpu(), gamma.grad.cpu()) < tol
+    assert rel_err((dbeta - 0.5).cpu(), beta.grad.cpu()) < tol
+    assert rel_err((dbias - 0.5).cpu(), y0.grad.sum(dim=(0, 2)).cpu()) < tol
+
+
 @pytest.mark.parametrize("case", ["n6_t6_c1024", "n13_t12_c512", "n5_t24_c256"])
 def test_all_taps_reduction_split_matches_unsplit(case):
     """Small-batch layers: the all-taps kernel cuts the input channels into slices, partial tiles meet in the registered
