@@ -144,6 +144,11 @@ RES_BLOCK_NODE = os.environ.get("MADIFF_RES_BLOCK", "1") != "0"
 ATTN_BLOCK_NODE = os.environ.get("MADIFF_ATTN_BLOCK", "1") != "0"
 
 
+def _chain_tag():
+    """A fresh ops.ChainTag for a pair of consecutive ResidualTemporalBlocks (None when the chained backward is off)."""
+    return ops.ChainTag() if (ops.FUSE_GNB_CHAIN and RES_BLOCK_NODE and torch.is_grad_enabled()) else None
+
+
 class ResidualTemporalBlock(nn.Module):
     """temporal.py:161-200.  keys: blocks.{0,1}.block.*, time_mlp.1.*, residual_conv.*"""
 
@@ -155,15 +160,18 @@ class ResidualTemporalBlock(nn.Module):
         self.residual_conv = nn.Conv1d(inp_channels, out_channels, 1) if inp_channels != out_channels else nn.Identity()
         self.out_channels = out_channels
 
-    def forward_cl(self, x, t, temb_proj, x2=None):
-        """x cl [N*t, Cin]; temb_proj fp32 [N, >=Cout] = Linear(Mish(t_emb)) (computed by the fused time GEMM)."""
+    def forward_cl(self, x, t, temb_proj, x2=None, chain_out=None, chain_in=None):
+        """x cl [N*t, Cin]; temb_proj fp32 [N, >=Cout] = Linear(Mish(t_emb)) (computed by the fused time GEMM).
+        chain_out / chain_in: the ops.ChainTag two consecutive blocks share when this block's output feeds the next block
+        only / this block's input is the previous block's output and nobody else's (the caller guarantees it)."""
         b0, b1 = self.blocks
         if RES_BLOCK_NODE and b0.spec is CONV5 and b1.spec is CONV5:        # the whole block as one autograd node
             rc = self.residual_conv if isinstance(self.residual_conv, nn.Conv1d) else None
             return ops.res_block(x, x2, temb_proj, t, b0.n_groups,
                                  (b0.block[0].weight, b0.block[0].bias, b0.block[2].weight, b0.block[2].bias),
                                  (b1.block[0].weight, b1.block[0].bias, b1.block[2].weight, b1.block[2].bias),
-                                 None if rc is None else rc.weight, None if rc is None else rc.bias)
+                                 None if rc is None else rc.weight, None if rc is None else rc.bias,
+                                 chain_out=chain_out, chain_in=chain_in)
         h = self.blocks[0].forward_cl(x, t, x2=x2, rowbias=temb_proj)
         if isinstance(self.residual_conv, nn.Conv1d):
             res = conv_gemm(x, [self.residual_conv.weight], [self.residual_conv.bias], CONV1, t, x2=x2)
@@ -372,18 +380,21 @@ class TemporalUnet(nn.Module):
         h, t = xcl, t_len
         skips = []
         for r1, r2, down in self.downs:
-            h = r1.forward_cl(h, t, bproj[bi]); bi += 1
-            h = r2.forward_cl(h, t, bproj[bi]); bi += 1
+            tag = _chain_tag()                  # r1's output feeds r2 only
+            h = r1.forward_cl(h, t, bproj[bi], chain_out=tag); bi += 1
+            h = r2.forward_cl(h, t, bproj[bi], chain_in=tag); bi += 1
             skips.append((h, t))
             if isinstance(down, Downsample1d):
                 h, t = down.forward_cl(h, t)
-        h = self.mid_block1.forward_cl(h, t, bproj[bi]); bi += 1
-        h = self.mid_block2.forward_cl(h, t, bproj[bi]); bi += 1
+        tag = _chain_tag()
+        h = self.mid_block1.forward_cl(h, t, bproj[bi], chain_out=tag); bi += 1
+        h = self.mid_block2.forward_cl(h, t, bproj[bi], chain_in=tag); bi += 1
         for r1, r2, up in self.ups:
             s, ts = skips.pop()
             assert ts == t, "skip/upsample length mismatch (horizon must be divisible by 2**(levels-1))"
-            h = r1.forward_cl(h, t, bproj[bi], x2=s); bi += 1
-            h = r2.forward_cl(h, t, bproj[bi]); bi += 1
+            tag = _chain_tag()
+            h = r1.forward_cl(h, t, bproj[bi], x2=s, chain_out=tag); bi += 1
+            h = r2.forward_cl(h, t, bproj[bi], chain_in=tag); bi += 1
             if isinstance(up, Upsample1d):
                 h, t = up.forward_cl(h, t)
         h = self.final_conv[0].forward_cl(h, t)
@@ -468,20 +479,23 @@ class SharedConvAttentionDeconv(nn.Module):
         h, t = xcl, t_len
         skips = []
         for r1, r2, down in net.downs:
-            h = r1.forward_cl(h, t, bproj[bi]); bi += 1
-            h = r2.forward_cl(h, t, bproj[bi]); bi += 1
+            tag = _chain_tag()                  # r1's output feeds r2 only
+            h = r1.forward_cl(h, t, bproj[bi], chain_out=tag); bi += 1
+            h = r2.forward_cl(h, t, bproj[bi], chain_in=tag); bi += 1
             skips.append((h, t))
             if isinstance(down, Downsample1d):
                 h, t = down.forward_cl(h, t)
-        h = net.mid_block1.forward_cl(h, t, bproj[bi]); bi += 1
-        h = net.mid_block2.forward_cl(h, t, bproj[bi]); bi += 1
+        tag = _chain_tag()
+        h = net.mid_block1.forward_cl(h, t, bproj[bi], chain_out=tag); bi += 1
+        h = net.mid_block2.forward_cl(h, t, bproj[bi], chain_in=tag); bi += 1
         h = self.self_attn[0].forward_cl(h, bsz, A, t, aproj[0])
         for j, (r1, r2, up) in enumerate(net.ups):
             s, ts = skips.pop()
             assert ts == t, "skip/upsample length mismatch (horizon must be divisible by 2**(levels-1))"
             s = self.self_attn[j + 1].forward_cl(s, bsz, A, t, aproj[j + 1])
-            h = r1.forward_cl(h, t, bproj[bi], x2=s); bi += 1
-            h = r2.forward_cl(h, t, bproj[bi]); bi += 1
+            tag = _chain_tag()
+            h = r1.forward_cl(h, t, bproj[bi], x2=s, chain_out=tag); bi += 1
+            h = r2.forward_cl(h, t, bproj[bi], chain_in=tag); bi += 1
             if isinstance(up, Upsample1d):
                 h, t = up.forward_cl(h, t)
         h = net.final_conv[0].forward_cl(h, t)

@@ -1143,25 +1143,48 @@ def _gn_backward(y, gamma, beta, stats, geom, dout, conv_bias=None, drb_slot=Non
 FUSE_DGRAD_GN_BWD = os.environ.get("MADIFF_FUSE_DGRAD_GN_BWD", "1") != "0"
 
 
-def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, drb_slot=None):
+FUSE_GNB_CHAIN = os.environ.get("MADIFF_GNB_CHAIN", "1") != "0"
+
+
+class ChainTag:
+    """What two CONSECUTIVE ResidualTemporalBlocks share when the first one's output feeds the second one only (the model
+    knows that; it hands the same tag to both, ResBlock chain_out / chain_in).  The first block's forward leaves what its
+    blocks[1] GroupNorm backward needs; the second block's backward then runs its blocks[0] data gradient with that
+    GroupNorm backward as the epilogue (madiff_conv_dgrad_gn_bwd_chain) and leaves the results for the first block's
+    backward, which skips its standalone GroupNorm-backward launch."""
+    __slots__ = ("y1", "st1", "geom1", "g1", "be1", "b1", "result", "dh")
+
+    def __init__(self):
+        self.y1 = self.st1 = self.geom1 = self.g1 = self.be1 = self.b1 = self.result = self.dh = None
+
+
+def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, drb_slot=None, addend=None, want_dh=False):
     """ResidualTemporalBlock backward, middle part, as ONE launch (madiff_conv_dgrad_gn_bwd): the data gradient of
     blocks[1]'s convolution with blocks[0]'s GroupNorm + Mish backward as its epilogue; dh never reaches memory.
     -> (dy0, dgamma0, dbeta0, dbias0, drowbias) or None when the layer is not covered (bf16 build, k5 "same" convolution,
-    channels a multiple of 128, whole groups inside 128 channels, T <= 32)."""
+    channels a multiple of 128, whole groups inside 128 channels, T <= 32).
+    want_dh (two consecutive blocks, ChainTag): the convolution is the NEXT block's blocks[0], dh = data gradient + addend
+    is stored as well (madiff_conv_dgrad_gn_bwd_chain) and returned as a sixth value."""
     if not FUSE_DGRAD_GN_BWD or _PRECISION != "bf16" or not dy1.is_cuda or g1.spec is not CONV5:
         return None
     n_seq, t, C, cpad, G, mode = geom0
+    if want_dh and (not FUSE_GNB_CHAIN or mode == 1 or g1.n_seq != n_seq or g1.t_out != t or g1.c1 != g1.cin):
+        return None
+    if addend is not None and (not want_dh or addend.shape != (n_seq * t, C) or addend.dtype != act_dtype()
+                               or addend.stride(1) != 1 or addend.stride(0) % 8 or addend.data_ptr() % 16):
+        return None
     npad = pad32(g1.osum)
     if cpad != C or C % 128 or g1.osum != npad or npad % 64 or g1.cin != C or t > 32 or y0 is None:
         return None
     Cg = C // G
     if C % G or Cg % 8 or 128 % Cg or (Cg // 8) & (Cg // 8 - 1):
         return None
-    sig = ("dgrad_gnb", n_seq, t, C, npad, G, mode)
+    sig = ("dgrad_gnb", n_seq, t, C, npad, G, mode) + (("chain", addend is not None) if want_dh else ())
     if _TUNE.get(sig) == "uncovered":
         return None
     Wf = _packed([w1], g1.spec, False)
     dy0 = torch.empty(n_seq * t, C, dtype=act_dtype(), device=dy1.device)
+    dh_out = torch.empty(n_seq * t, C, dtype=act_dtype(), device=dy1.device) if want_dh else None
     drb = None
     if mode == 1:
         drb = slot_view(drb_slot, n_seq, C)
@@ -1169,6 +1192,14 @@ def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, dr
             drb = torch.empty(n_seq, C, dtype=torch.float32, device=dy1.device)
 
     def launch(variant, dst):
+        if want_dh:
+            return lib.call_rc("madiff_conv_dgrad_gn_bwd_chain", dy1.data_ptr(), dy1.stride(0), n_seq * t, npad, t,
+                               Wf.data_ptr(), Wf.stride(0), g1.cin, C, y0.data_ptr(), y0.stride(0), gamma0.data_ptr(),
+                               beta0.data_ptr(), stats0[0].data_ptr(), stats0[1].data_ptr(), G, dy0.data_ptr(),
+                               dy0.stride(0), dst[0].data_ptr(), dst[1].data_ptr(),
+                               dst[2].data_ptr() if bias0 is not None else None, _p(addend),
+                               0 if addend is None else addend.stride(0), dh_out.data_ptr(), dh_out.stride(0), variant,
+                               _stream())
         return lib.call_rc("madiff_conv_dgrad_gn_bwd", dy1.data_ptr(), dy1.stride(0), n_seq * t, npad, t, Wf.data_ptr(),
                            Wf.stride(0), g1.cin, C, y0.data_ptr(), y0.stride(0), gamma0.data_ptr(), beta0.data_ptr(),
                            stats0[0].data_ptr(), stats0[1].data_ptr(), G, dy0.data_ptr(), dy0.stride(0), dst[0].data_ptr(),
@@ -1184,7 +1215,9 @@ def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, dr
         if variant >= 0:
 
             def unfused():
-                dh = _dgrad_wt(dy1, n_seq * t, npad, g1.spec, t, t, Wf, g1.cin, 0, C, C)
+                dh = _dgrad_wt(dy1, n_seq * t, npad, g1.spec, t, t, Wf, g1.cin, 0, C, C, addend=addend)
+                if dh is not None and addend is not None and not _dgrad_wt.fused_add:
+                    dh = dh + addend
                 if dh is not None:
                     lib.call("madiff_gn_mish_bwd", _dt(), y0.data_ptr(), y0.stride(0), dh.data_ptr(), dh.stride(0),
                              dy0.data_ptr(), dy0.stride(0), gamma0.data_ptr(), beta0.data_ptr(), stats0[0].data_ptr(),
@@ -1212,11 +1245,14 @@ def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, dr
 
     # its own family in the timing records (rocprofv3 shows it as the GNB = true instantiation): the launch carries the
     # data gradient's FLOPs plus the GroupNorm backward's traffic (read y, write dy; dh stays on chip)
-    _timed("conv_taps_bf16_kernel<GNB>", g1.flops, run, nbytes=float(2 * n_seq * t * C * dy1.element_size()))
+    _timed("conv_taps_bf16_kernel<GNB>", g1.flops, run,
+           nbytes=float((2 + int(want_dh) + int(addend is not None)) * n_seq * t * C * dy1.element_size()))
     if rc[0]:
         _TUNE[sig] = "uncovered"
         return None
     outs = _gn_param_outs(plist, views, bufs, bias0)
+    if want_dh:
+        return dy0, outs[0], outs[1], outs[2], drb, dh_out
     return dy0, outs[0], outs[1], outs[2], drb
 
 
@@ -1337,10 +1373,11 @@ class ResBlock(torch.autograd.Function):
     instead of torch adding the two contributions in a separate pass, the residual one is handed to blocks[0]'s
     data-gradient kernel as an addend.
 
-    apply(x, x2, temb, t_in, G, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb)   (rw / rb None: identity residual)"""
+    apply(x, x2, temb, t_in, G, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb, chain_out, chain_in)
+    (rw / rb None: identity residual; chain_out / chain_in: ChainTag | None, see there)"""
 
     @staticmethod
-    def forward(ctx, x, x2, temb, t_in: int, G: int, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb):
+    def forward(ctx, x, x2, temb, t_in: int, G: int, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb, chain_out=None, chain_in=None):
         need = any(ctx.needs_input_grad)
 
         def block(xa, xb, rowbias, res, w, b, gamma, beta):
@@ -1361,6 +1398,13 @@ class ResBlock(torch.autograd.Function):
         ctx.save_for_backward(x, x2, y0, st0, h, y1, st1, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb)
         ctx.geo = (cg0, geom0, cgr, cg1, geom1)
         ctx.temb_slot = grad_slot(temb)
+        ctx.chain_out = ctx.chain_in = None
+        if need and chain_out is not None and y1 is not None:
+            chain_out.y1, chain_out.st1, chain_out.geom1 = y1, st1, geom1
+            chain_out.g1, chain_out.be1, chain_out.b1 = g1, be1, b1
+            ctx.chain_out = chain_out
+        if need and chain_in is not None and chain_in.y1 is not None and x2 is None:
+            ctx.chain_in = chain_in
         return out
 
     @staticmethod
@@ -1371,7 +1415,14 @@ class ResBlock(torch.autograd.Function):
         dout = dout.contiguous()
         if dout.dtype != act_dtype():
             dout = dout.to(act_dtype())
-        dy1, dgamma1, dbeta1, dbias1, _, _ = _gn_backward(y1, g1, be1, st1, geom1, dout, conv_bias=b1)
+        tag = ctx.chain_out
+        if tag is not None and tag.result is not None:
+            # the next block's backward already took dout (it produced it) through this block's blocks[1] GroupNorm backward
+            if tag.dh is None or tag.dh.data_ptr() != dout.data_ptr():
+                raise RuntimeError("chained residual blocks: the first block's output has another consumer")
+            (dy1, dgamma1, dbeta1, dbias1), tag.result, tag.dh = tag.result, None, None
+        else:
+            dy1, dgamma1, dbeta1, dbias1, _, _ = _gn_backward(y1, g1, be1, st1, geom1, dout, conv_bias=b1)
         # blocks[1]'s data gradient with blocks[0]'s GroupNorm backward in its epilogue (one launch, no dh), else separately
         fused = _dgrad_gn_bwd_fused(cg1, w1, dy1, y0, st0, geom0, g0, be0, b0, ctx.temb_slot)
         if fused is not None:
@@ -1389,17 +1440,29 @@ class ResBlock(torch.autograd.Function):
         else:
             dy0, dgamma0, dbeta0, dbias0, drb, _ = _gn_backward(y0, g0, be0, st0, geom0, dh, conv_bias=b0,
                                                                 drb_slot=ctx.temb_slot)
-        dx, dx2, _, gw0, _ = _conv_backward(cg0, x, x2, [w0], [b0], dy0, needs[0], needs[1], [needs[5]], "none", False,
-                                            addends=(dxr, dx2r))
+        chained = None
+        tin = ctx.chain_in
+        if tin is not None and needs[0] and x2 is None:
+            # this block's input is the previous block's output and nobody else's: blocks[0]'s data gradient (+ the residual
+            # branch's gradient) IS the previous block's dout -- run that block's blocks[1] GroupNorm backward in the epilogue
+            chained = _dgrad_gn_bwd_fused(cg0, w0, dy0, tin.y1, tin.st1, tin.geom1, tin.g1, tin.be1, tin.b1, None,
+                                          addend=dxr, want_dh=True)
+        if chained is not None:
+            tin.result, tin.dh = (chained[0], chained[1], chained[2], chained[3]), chained[5]
+            dx, dx2 = chained[5], None
+            _, _, _, gw0, _ = _conv_backward(cg0, x, x2, [w0], [b0], dy0, False, False, [needs[5]], "none", False)
+        else:
+            dx, dx2, _, gw0, _ = _conv_backward(cg0, x, x2, [w0], [b0], dy0, needs[0], needs[1], [needs[5]], "none", False,
+                                                addends=(dxr, dx2r))
         return (dx, dx2, drb if needs[2] else None, None, None, gw0[0], dbias0, dgamma0, dbeta0, gw1[0], dbias1, dgamma1,
-                dbeta1, gwr[0], gbr[0])
+                dbeta1, gwr[0], gbr[0], None, None)
 
 
-def res_block(x, x2, temb, t_in: int, G: int, blk0, blk1, rw=None, rb=None):
-    """blk0 / blk1 = (weight, bias, gamma, beta) of the two Conv1dBlocks."""
+def res_block(x, x2, temb, t_in: int, G: int, blk0, blk1, rw=None, rb=None, chain_out=None, chain_in=None):
+    """blk0 / blk1 = (weight, bias, gamma, beta) of the two Conv1dBlocks; chain_out / chain_in: ChainTag | None."""
     if x2 is not None and x.shape[1] % 128 != 0:   # the split-source kernels need 128-aligned halves
         x, x2 = torch.cat((x, x2), dim=1), None
-    return ResBlock.apply(x, x2, temb, t_in, G, *blk0, *blk1, rw, rb)
+    return ResBlock.apply(x, x2, temb, t_in, G, *blk0, *blk1, rw, rb, chain_out, chain_in)
 
 
 def conv_block(x, w, b, gamma, beta, spec: ConvSpec, t_in: int, G: int, x2=None, rowbias=None, res=None):

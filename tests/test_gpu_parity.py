@@ -570,3 +570,55 @@ def test_full_size_properties():
             assert rel_err(yp.cpu(), y[perm].cpu()) < tol, prec
     finally:
         ops.set_precision("bf16")
+
+
+def test_chained_residual_blocks_backward_matches_unchained():
+    """Two consecutive ResidualTemporalBlocks share an ops.ChainTag: the second block's blocks[0] data gradient runs the
+    first block's blocks[1] GroupNorm backward as its epilogue (madiff_conv_dgrad_gn_bwd_chain).  Full-width denoiser,
+    timing decisions off so that every covered pair takes the chained path: six standalone GroupNorm-backward calls
+    disappear (three down pairs, the middle pair, two up pairs), and every gradient agrees with the unchained backward
+    to bf16 rounding."""
+    from madiff_amd import ops
+    ops.set_precision("bf16")
+    dev = torch.device("cuda:0")
+    dif, _ = build("tag4", 128, K=8)
+    net = dif.model
+    for a in net.self_attn:
+        a.gamma.data.fill_(0.5)
+    A, Tt, Fd, hh = SHAPES["tag4"]
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(6, Tt, A, Fd, generator=gen).to(dev)
+    t = torch.randint(0, 8, (6,), generator=gen).to(dev)
+    r = torch.rand(6, 1, A, generator=gen).to(dev)
+    gy = torch.randn(6, Tt, A, Fd, generator=gen).to(dev)
+    old_chain, old_tune, real_gn = ops.FUSE_GNB_CHAIN, ops._AUTOTUNE, ops._gn_backward
+    calls = [0]
+
+    def counting(*a, **k):
+        calls[0] += 1
+        return real_gn(*a, **k)
+
+    res = {}
+    try:
+        ops._AUTOTUNE = False
+        ops._gn_backward = counting
+        for chain in (False, True):
+            ops.FUSE_GNB_CHAIN = chain
+            calls[0] = 0
+            net.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_(True)
+            y = net(xg, t, returns=r, use_dropout=False)
+            y.backward(gy)
+            res[chain] = (calls[0], xg.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    finally:
+        ops.FUSE_GNB_CHAIN, ops._AUTOTUNE, ops._gn_backward = old_chain, old_tune, real_gn
+    assert res[False][0] - res[True][0] == 6, (res[False][0], res[True][0])
+    assert l2_err(res[True][1].cpu(), res[False][1].cpu()) < 2e-2
+    assert res[True][2].keys() == res[False][2].keys()
+    scale = max(float(g.abs().max()) for g in res[False][2].values())
+    for n, g0 in res[False][2].items():
+        g1 = res[True][2][n]
+        if float(g0.abs().max()) < 5e-3 * scale:            # cancellation residues (see sampled_gradient_check)
+            assert float((g1 - g0).abs().max()) < 2e-3 * scale, n
+        else:
+            assert l2_err(g1.cpu(), g0.cpu()) < 3e-2, n
