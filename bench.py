@@ -268,7 +268,7 @@ def main():
     torch.manual_seed(0)
     dif = build(device)
     ema = copy.deepcopy(dif)
-    opt = FlatAdamEMA(dif, ema, lr=2e-4, ema_decay=0.995, bucket_mb=32.0)
+    opt = FlatAdamEMA(dif, ema, lr=2e-4, ema_decay=0.995, bucket_mb=float(os.environ.get("MADIFF_BENCH_BUCKET_MB", "64")))
     opt.broadcast_parameters(0)
     batch = synthetic_batch(BATCH, device, seed=rank)
 
