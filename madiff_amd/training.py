@@ -124,7 +124,7 @@ class Trainer(object):
     def __init__(self, diffusion_model, dataset, renderer, ema_decay=0.995, train_batch_size=32, train_lr=2e-5,
                  gradient_accumulate_every=2, step_start_ema=2000, update_ema_every=10, log_freq=100, sample_freq=1000,
                  save_freq=1000, label_freq=100000, eval_freq=100000, save_parallel=False, n_reference=8, bucket=None,
-                 train_device="cuda", save_checkpoints=False, use_graph: Optional[bool] = None, bucket_mb: float = 32.0,
+                 train_device="cuda", save_checkpoints=False, use_graph: Optional[bool] = None, bucket_mb: float = 64.0,
                  shuffle: bool = True, seed: int = 0, allow_eager_fallback: Optional[bool] = None):
         """Reference arguments (training.py:43-64) plus: use_graph (None = replay the step from a hipGraph on a GPU),
         bucket_mb (gradient bucket size of the data-parallel all-reduce / optimizer slices), shuffle, seed.
