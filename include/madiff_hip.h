@@ -81,8 +81,13 @@ int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, const void* 
    environments) are cut into slices of the input channels; partial tiles meet in `ws` and the last workgroup to arrive
    finishes the tile (bias / GroupNorm epilogues unchanged, summation order fixed).  ws: device memory, 16-byte aligned,
    `bytes` long; counters: n_counters zeroed ints (they reset themselves).  One registration per device (the current one);
-   ws = NULL unregisters.  Launches using it must be stream-ordered on that GPU. */
+   ws = NULL unregisters.  The arena is cut into 16 equal slots (bytes / 16 and n_counters / 16 each) and a slot is owned
+   by one issue order: an eager stream, or one stream of one stream capture -- so launches that may overlap on the GPU
+   (two streams, two graphs, two branches of a graph) never share partial tiles or tickets.  Slots are not handed on; once
+   all are owned, further streams / captures run unsplit.  A launch that faults may leave tickets non-zero: register again.
+   madiff_splitk_slots_used(): slots handed out on the current device so far. */
 int madiff_set_splitk_workspace(void* ws, long bytes, int* counters, int n_counters);
+int madiff_splitk_slots_used(void);
 int madiff_gemm_tile_count(void);
 /* rows / columns / LDS stages of variant `tile`; returns 1 when madiff_gemm_dgrad_wt offers it too, 0 when not, -1 when
  * the id is invalid. */
@@ -238,8 +243,10 @@ int madiff_loss_fwd(const float* eps, const float* noise, const float* w, const 
  * and neither this call nor anything it calls allocates or frees.  Forward only (loss evaluation / logging).  Limit:
  * B <= 16384; beyond it the call launches nothing and returns -2.  Calls that overlap on one GPU share the array and
  * race; calls on one stream are ordered.  madiff_loss_static_init() resolves the array's device address for the current
- * GPU (hipGetSymbolAddress); the entry point does the same on its first call on a device, so the init call is only needed
- * where even that must happen at set-up time (e.g. before a capture). */
+ * GPU (hipGetSymbolAddress; idempotent, thread-safe); the entry point does the same on its first EAGER call on a device.
+ * Resolving a symbol may load code or allocate, which is not legal inside a stream capture: madiff_loss_static_init() MUST
+ * have been called once per device before a capture that contains this entry point -- if it was not, the call launches
+ * nothing and returns -3. */
 int madiff_loss_static_init(void);
 int madiff_loss_fwd_static(const float* eps, const float* noise, const float* w, const void* masks, int masks_f64,
                            const float* pred, long pred_rs, long pred_as, const float* x, const float* legal, int B, int T,

@@ -14,6 +14,7 @@
 // Tiles are 128x128 per 256-thread workgroup (4 waves, 64x64 each), operands staged through LDS with
 // register prefetch + double buffering; the conv taps are realised as shifted row gathers while
 // staging, so no im2col matrix ever exists in memory.
+#include <mutex>
 #include "gemm_params.h"
 #include <stdlib.h>
 
@@ -387,28 +388,65 @@ static int pick_tile(int M, int Npad, int wt) {
 }
 
 // ---- workspace of the all-taps kernel's reduction split (conv_taps_bf16.hip, p.cks): registered once per device by the
-// host (madiff_amd/ops.py allocates 64 MB + 4096 zeroed counters on first use).  The counters reset themselves; launches
-// that use the workspace must be ordered on the GPU (the product issues every all-taps launch on the step's main stream).
+// host (madiff_amd/ops.py allocates it on first use).  The partial tiles and tickets of a launch are indexed by tile id only,
+// so two launches that may overlap on the GPU must not share them: the registered arena is cut into MADIFF_WS_SLOTS equal
+// slots and a slot belongs to ONE issue order -- an eager stream (keyed by its handle), or one stream of one capture (keyed
+// by the stream handle AND the capture's unique id, so two graphs never share a slot even when their capture streams reuse
+// a handle, and neither do two parallel branches of one capture).  Launches of one stream / one captured branch are
+// ordered by construction.  A slot is never handed on; when they are used up, later
+// streams / captures simply run unsplit (cks = 1).  The counters reset themselves at the end of every launch.
 #define MADIFF_MAX_DEV 64
-static float* g_ws[MADIFF_MAX_DEV];
-static long g_ws_floats[MADIFF_MAX_DEV];
-static int* g_ws_cnt[MADIFF_MAX_DEV];
-static int g_ws_ncnt[MADIFF_MAX_DEV];
+#define MADIFF_WS_SLOTS 16
+struct WsArena {
+  float* ws; long slot_floats; int* cnt; int slot_ncnt;
+  int used; unsigned long long key[MADIFF_WS_SLOTS], cap[MADIFF_WS_SLOTS];
+};
+static WsArena g_arena[MADIFF_MAX_DEV];
+static std::mutex g_arena_mu;
 
 extern "C" int madiff_set_splitk_workspace(void* ws, long bytes, int* counters, int n_counters) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MADIFF_MAX_DEV) return -1;
   if (ws && (((size_t)ws % 16) || bytes < 0 || !counters || n_counters <= 0)) return -1;
-  g_ws[dev] = (float*)ws; g_ws_floats[dev] = ws ? bytes / 4 : 0; g_ws_cnt[dev] = ws ? counters : nullptr;
-  g_ws_ncnt[dev] = ws ? n_counters : 0;
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  WsArena& a = g_arena[dev];
+  a.ws = (float*)ws; a.cnt = ws ? counters : nullptr; a.used = 0;
+  a.slot_floats = ws ? (bytes / 4 / MADIFF_WS_SLOTS) & ~3L : 0;          // slots stay 16-byte aligned
+  a.slot_ncnt = ws ? n_counters / MADIFF_WS_SLOTS : 0;
   return 0;
 }
 
-static void attach_ws(GemmFwdParams& p) {
+// number of slots handed out on the current device so far (tests)
+extern "C" int madiff_splitk_slots_used(void) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MADIFF_MAX_DEV) return -1;
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  return g_arena[dev].used;
+}
+
+static void attach_ws(GemmFwdParams& p, hipStream_t stream) {
   int dev = -1;
   p.ws = nullptr; p.ws_floats = 0; p.ws_cnt = nullptr; p.ws_ncnt = 0; p.cks = 1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MADIFF_MAX_DEV) return;
-  p.ws = g_ws[dev]; p.ws_floats = g_ws_floats[dev]; p.ws_cnt = g_ws_cnt[dev]; p.ws_ncnt = g_ws_ncnt[dev];
+  // issue order this launch belongs to: (stream, 0) eagerly, (stream, capture id) while the stream is capturing
+  const unsigned long long key = (unsigned long long)(size_t)stream;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  unsigned long long cid = 0;
+  if (!(hipStreamGetCaptureInfo(stream, &cs, &cid) == hipSuccess && cs == hipStreamCaptureStatusActive)) cid = 0;
+  else cid |= 1ull << 63;
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  WsArena& a = g_arena[dev];
+  if (!a.ws || a.slot_floats <= 0 || a.slot_ncnt <= 0) return;
+  int slot = -1;
+  for (int i = 0; i < a.used; i++)
+    if (a.key[i] == key && a.cap[i] == cid) { slot = i; break; }
+  if (slot < 0) {
+    if (a.used >= MADIFF_WS_SLOTS) return;             // every slot has an owner: this issue order runs unsplit
+    slot = a.used++;
+    a.key[slot] = key; a.cap[slot] = cid;
+  }
+  p.ws = a.ws + (size_t)slot * a.slot_floats; p.ws_floats = a.slot_floats;
+  p.ws_cnt = a.cnt + (size_t)slot * a.slot_ncnt; p.ws_ncnt = a.slot_ncnt;
 }
 
 static int xcd_on() {
@@ -448,7 +486,7 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
   p.rm = RowMap{T_out, T_in, stride, pad, tr};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Npad; p.bias = bias; p.rowbias = rowbias; p.ldrb = ldrb;
   p.C = C; p.ldc = ldc; p.act = act; p.permT = permT; p.permA = permA;
-  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p);
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p, stream);
   dim3 grid((M + 127) / 128, (Npad + 127) / 128), block(256);
   if (tile >= kFirstTapsTile) {
     if (dtype != MADIFF_BF16 || !use_dma_kernel()) return 1;
@@ -487,7 +525,7 @@ extern "C" int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, i
   p.rm = RowMap{T, T, 1, 2, 0};
   p.W = W; p.ldw = ldw; p.Nout = Nout; p.Npad = Nout; p.bias = bias; p.rowbias = nullptr; p.ldrb = 0;
   p.C = Y; p.ldc = ldy; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p);
+  p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p, stream);
   return madiff_launch_conv_taps_gn_bf16(&p, variant, out, ldo, gamma, beta, mean, rstd, G, eps, mode, rowbias, ldrb, res,
                                          ldr, Y != nullptr, stream);
 }
@@ -532,7 +570,7 @@ extern "C" int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred
   p.W = (const unsigned char*)W + (size_t)wcol0 * 2; p.ldw = ldw; p.Nout = Ncols; p.Npad = Npad;
   p.bias = nullptr; p.rowbias = nullptr; p.ldrb = 0;
   p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0; p.addend = addend; p.lda = ld_add; p.xcd = xcd_on(); attach_ws(p);
+  p.wt = 1; p.wtap = wtap; p.wcols = wtap - wcol0; p.addend = addend; p.lda = ld_add; p.xcd = xcd_on(); attach_ws(p, stream);
   const int nsteps = (Kred / 64) * taps;
   p.ksplit = ksplit > 1 ? (ksplit < nsteps ? ksplit : nsteps) : 0;
   if (p.ksplit > 1) {
@@ -606,7 +644,7 @@ static int dgrad_gn_bwd_impl(const void* dY, int ldy, int M, int Kred, int T, co
   p.W = W; p.ldw = ldw; p.Nout = Ncols; p.Npad = Ncols;
   p.bias = nullptr; p.rowbias = nullptr; p.ldrb = 0;
   p.C = dX; p.ldc = ldx; p.act = 0; p.permT = 0; p.permA = 0;
-  p.wt = 1; p.wtap = wtap; p.wcols = wtap; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p);
+  p.wt = 1; p.wtap = wtap; p.wcols = wtap; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p, stream);
   return madiff_launch_conv_taps_gnb_bf16(&p, variant, Ypre, ldyp, gamma, beta, mean, rstd, G, dgamma, dbeta, dbias, drowbias,
                                           ldrb, addend, ld_add, dH, ldh, stream);
 }

@@ -7,6 +7,7 @@
 // Layouts: eps / noise [B,T,A,F] fp32; w [T,A,F]; masks [B,T,A] (fp64 as the dataset delivers them, or fp32);
 // x [B,T,A,act+F] fp32 (actions first); legal [B,T,A,nout] fp32 or null; inverse-dynamics predictions pred: element
 // (r = (b, t < T-1), a, o) at pred[r*pred_rs + a*pred_as + o] (shared MLP: one row per (r, a); joint MLP: one row per r).
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -270,19 +271,24 @@ extern "C" int madiff_loss_fwd(const float* eps, const float* noise, const float
 #define MADIFF_LOSS_STATIC_BYTES (MADIFF_LOSS_WS_DOUBLES * 8 + MADIFF_LOSS_STATIC_MAX_B * 3 * 4)
 static __device__ __align__(256) unsigned char scratch[MADIFF_LOSS_STATIC_BYTES];   // 1.5 KB + 192 KB per GPU
 #define MADIFF_MAX_DEVICES 64
-static void* g_scratch_ptr[MADIFF_MAX_DEVICES];   // device address of `scratch` on each GPU (the array's name is a host-side stand-in)
+// device address of `scratch` on each GPU (the array's name is a host-side stand-in).  Atomic: concurrent first calls from
+// several threads may both resolve the symbol; they store the same value.
+static std::atomic<void*> g_scratch_ptr[MADIFF_MAX_DEVICES];
 
+// Resolves this GPU's copy of the scratch array.  Call once per device, with that device current, BEFORE any stream capture
+// that contains madiff_loss_fwd_static: resolving a symbol may load the code object / allocate, which is not legal inside a
+// capture.  Idempotent, thread-safe.
 extern "C" int madiff_loss_static_init(void) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   if (dev < 0 || dev >= MADIFF_MAX_DEVICES) return -1;
-  if (g_scratch_ptr[dev]) return 0;
+  if (g_scratch_ptr[dev].load(std::memory_order_acquire)) return 0;
   void* ptr = nullptr;
   e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
   if (e != hipSuccess) return (int)e;
   if (!ptr) return -1;
-  g_scratch_ptr[dev] = ptr;
+  g_scratch_ptr[dev].store(ptr, std::memory_order_release);
   return 0;
 }
 
@@ -293,12 +299,19 @@ extern "C" int madiff_loss_fwd_static(const float* eps, const float* noise, cons
   LossArgs p{eps, noise, w, masks, masks_f64, pred, pred_rs, pred_as, x, legal, B, T, A, F, act, nout, discrete, 1};
   if (loss_check(p) || !out || !out_f) return -1;
   if (B > MADIFF_LOSS_STATIC_MAX_B) return -2;            // beyond the static scratch: use madiff_loss_fwd with a workspace
-  int rc = madiff_loss_static_init();                     // (first call on this device; a no-op afterwards)
-  if (rc) return rc;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
-  unsigned char* base = (unsigned char*)g_scratch_ptr[dev];
+  if (dev < 0 || dev >= MADIFF_MAX_DEVICES) return -1;
+  if (!g_scratch_ptr[dev].load(std::memory_order_acquire)) {
+    // first call on this device.  Under capture the symbol must not be resolved here (it may load code / allocate):
+    // -3 = "call madiff_loss_static_init() on this device before capturing"
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return -3;
+    int rc = madiff_loss_static_init();
+    if (rc) return rc;
+  }
+  unsigned char* base = (unsigned char*)g_scratch_ptr[dev].load(std::memory_order_acquire);
   double* ws = (double*)base;
   float* mse_sums = (float*)(base + MADIFF_LOSS_WS_DOUBLES * 8);
   return loss_fwd_impl(p, mse_sums, ws, out, out_f, stream);

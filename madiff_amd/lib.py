@@ -31,6 +31,7 @@ _SIGS = {
                                 _f, _i, _vp, _i, _vp, _i, _i, _vp],
     "madiff_gemm_tile_count": [],
     "madiff_set_splitk_workspace": [_vp, _l, _vp, _i],
+    "madiff_splitk_slots_used": [],
     "madiff_gemm_tile_info": [_i, _vp, _vp, _vp],
     "madiff_gemm_dgrad_wt": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
     "madiff_gemm_dgrad_wt_add": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],

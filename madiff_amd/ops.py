@@ -53,6 +53,7 @@ def pad32(c: int) -> int:
 
 _SPLITK_WS: dict = {}          # device index -> (workspace, counters) registered with the library (kept alive here)
 SPLITK_WS_MB = int(os.environ.get("MADIFF_SPLITK_WS_MB", "64"))
+SPLITK_WS_SLOTS = 16           # = MADIFF_WS_SLOTS of csrc/gemm.hip
 
 
 def _ensure_splitk_workspace() -> None:
@@ -61,8 +62,10 @@ def _ensure_splitk_workspace() -> None:
     dev = torch.cuda.current_device()
     if dev in _SPLITK_WS or SPLITK_WS_MB <= 0 or torch.cuda.is_current_stream_capturing():
         return
-    ws = torch.empty(SPLITK_WS_MB << 20, dtype=torch.uint8, device=f"cuda:{dev}")
-    cnt = torch.zeros(4096, dtype=torch.int32, device=f"cuda:{dev}")
+    # SPLITK_WS_SLOTS slots of SPLITK_WS_MB each: the library hands one slot to every stream / capture that uses the split
+    # (launches that may overlap never share partial tiles or tickets, csrc/gemm.hip attach_ws)
+    ws = torch.empty((SPLITK_WS_MB << 20) * SPLITK_WS_SLOTS, dtype=torch.uint8, device=f"cuda:{dev}")
+    cnt = torch.zeros(1024 * SPLITK_WS_SLOTS, dtype=torch.int32, device=f"cuda:{dev}")
     lib.call("madiff_set_splitk_workspace", ws.data_ptr(), ws.numel(), cnt.data_ptr(), cnt.numel())
     _SPLITK_WS[dev] = (ws, cnt)
 
@@ -924,7 +927,22 @@ WGRAD_SIDE_STREAM = os.environ.get("MADIFF_WGRAD_SIDE_STREAM", "1") != "0"
 FUSE_BIAS_WGRAD = os.environ.get("MADIFF_FUSE_BIAS_WGRAD", "1") != "0"
 # parameter-gradient launches go round-robin over this many auxiliary streams (parallel branches of the captured step)
 WGRAD_STREAMS = int(os.environ.get("MADIFF_WGRAD_STREAMS", "4"))
-_WGRAD_RR = 0
+
+
+def wgrad_branch_name(sink, weights) -> str:
+    """The auxiliary stream a layer's parameter-gradient launch goes to.  The branch belongs to the PARAMETER (assigned in
+    turn the first time the layer's weight is seen, then remembered in the sink), not to the launch: the launch is a
+    non-atomic read-modify-write of the flat gradient, so two launches for one parameter -- the micro-batches of an
+    unfolded accumulation step -- must be ordered, which the same stream (and, in a captured step, the chain of nodes it
+    becomes) guarantees.  A global launch counter put them on different branches with no edge between them."""
+    if WGRAD_STREAMS <= 1:
+        return "wgrad"
+    table = sink.__dict__.setdefault("_wgrad_branch", {})
+    key = id(weights[0])
+    ent = table.get(key)
+    if ent is None or ent[0]() is not weights[0]:
+        ent = table[key] = (weakref.ref(weights[0]), len(table) % WGRAD_STREAMS)
+    return "wgrad%d" % ent[1]
 
 
 def _param_grads_side(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
@@ -939,9 +957,7 @@ def _param_grads_side(g, x, x2, weights, biases, dy, need_w, bias_mode, gw):
             and (bias_mode != "colsum" or all(_sink_view(b) is not None for b in biases))):
         return _param_grads(g, x, x2, weights, biases, dy, need_w, bias_mode, gw)
     cur = torch.cuda.current_stream()
-    global _WGRAD_RR
-    side = aux_stream(dy.device, "wgrad" if WGRAD_STREAMS <= 1 else "wgrad%d" % (_WGRAD_RR % WGRAD_STREAMS))
-    _WGRAD_RR += 1
+    side = aux_stream(dy.device, wgrad_branch_name(sink, weights))
     wait_stream(side, cur)
     sink.deferred = []
     try:

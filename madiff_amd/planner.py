@@ -80,11 +80,13 @@ class DevicePlanner:
     def push_obs(self, obs: torch.Tensor) -> torch.Tensor:
         """`obs_queue.append(obs); np.stack(list(obs_queue), axis=1)` (evaluator.py:273-275) on the device: drops the
         oldest entry, appends the normalised observation [B, A, F], returns the history [B, hh+1, A, F] (newest last)."""
-        h = self._hist
+        h = getattr(self, "_hist", None)
+        if h is None:
+            raise RuntimeError("DevicePlanner.push_obs: call reset_history(first_obs) at the start of an episode batch")
         if self.hh > 0:
             h[:, :-1] = h[:, 1:].clone()
         h[:, -1] = obs.to(h.dtype)
-        return h
+        return h.clone()          # a fresh tensor per step, like the evaluator's np.stack: callers may keep it
 
     # ------------------------------------------------------------------ sampling (evaluator.py:85-134)
     @torch.no_grad()

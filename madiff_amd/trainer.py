@@ -77,7 +77,14 @@ class FlatAdamEMA:
         self.params = [p for _, p in named]
         dev = self.params[0].device
         if self.use_hip is None:
-            self.use_hip = dev.type == "cuda"
+            if dev.type != "cuda":
+                # the product optimizer is the HIP kernel; the host-arithmetic branch below exists for the gloo tests of
+                # the data-parallel machinery and has to be asked for by name
+                raise RuntimeError("FlatAdamEMA: the module is not on a GPU.  The fused Adam/EMA step is a HIP kernel; pass "
+                                   "use_hip_kernel=False explicitly to run the host-arithmetic test path")
+            self.use_hip = True
+        elif self.use_hip and dev.type != "cuda":
+            raise RuntimeError("FlatAdamEMA(use_hip_kernel=True) needs the module on a GPU")
         # ---- flat layout.  Weight matrices of GEMM layers are stored in the GEMM's own layout [O, taps, pad32(I)]
         # (pad columns stay 0: zero gradient -> zero Adam update), members of a fused group (q/k/v, the time-MLP
         # bundle) back to back; the nn.Parameter becomes a strided view with the reference's shape.  Adam/EMA are
@@ -456,13 +463,26 @@ def can_fold(diffusion, batches) -> bool:
     x0 = batches[0]["x"]
     if not (x0.is_cuda and x0.dtype == torch.float32):
         return False
-    keys = set(batches[0].keys())
-    return all(set(b.keys()) == keys and b["x"].shape == x0.shape for b in batches)
+    def same(vals):
+        """Every micro-batch holds the same kind of leaf here: all None, or tensors of one shape / dtype (nested dicts
+        likewise).  Anything else (a Python scalar, a ragged field) is left to the unfolded loop, which accepts it."""
+        v0 = vals[0]
+        if v0 is None:
+            return all(v is None for v in vals)
+        if isinstance(v0, dict):
+            return (all(isinstance(v, dict) and set(v.keys()) == set(v0.keys()) for v in vals)
+                    and all(same([v[k] for v in vals]) for k in v0))
+        return torch.is_tensor(v0) and all(torch.is_tensor(v) and v.shape == v0.shape and v.dtype == v0.dtype
+                                           and v.device == v0.device for v in vals)
+
+    return same(list(batches))
 
 
 def fold_batches(batches):
     """Concatenate batch dicts (nested dicts of tensors) along the batch axis."""
     def cat(vals):
+        if vals[0] is None:                 # a field every micro-batch leaves out (legal_actions=None, env_ts=None)
+            return None
         if isinstance(vals[0], dict):
             return {k: cat([v[k] for v in vals]) for k in vals[0]}
         return torch.cat(vals, dim=0)

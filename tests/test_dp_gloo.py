@@ -119,3 +119,31 @@ def test_bucket_dtype_is_validated():
     from madiff_amd.trainer import FlatAdamEMA
     with pytest.raises(ValueError):
         FlatAdamEMA(_model(), None, bucket_dtype="fp8")
+
+
+def test_host_arithmetic_optimizer_must_be_asked_for():
+    """The fused Adam/EMA step is a HIP kernel.  The torch host-arithmetic branch exists for the gloo tests above only: a
+    module that is not on a GPU raises unless use_hip_kernel=False is passed explicitly (no silent second path)."""
+    from madiff_amd.trainer import FlatAdamEMA
+    m = _model()
+    x, y = _data()
+    ((m(x[0]) - y[0]) ** 2).mean().backward()
+    opt = FlatAdamEMA(m, None, lr=1e-2)
+    with pytest.raises(RuntimeError, match="use_hip_kernel=False"):
+        opt.step()
+    with pytest.raises(RuntimeError, match="needs the module on a GPU"):
+        FlatAdamEMA(m, None, lr=1e-2, use_hip_kernel=True).step()
+    FlatAdamEMA(m, None, lr=1e-2, use_hip_kernel=False).step()          # the explicit flag still works
+
+
+def test_wgrad_branch_belongs_to_the_parameter():
+    """Parameter-gradient launches are read-modify-writes of the flat gradient: both launches for one parameter (the
+    micro-batches of an unfolded accumulation step) must go to the same auxiliary stream, whatever was issued between."""
+    from madiff_amd import ops
+    sink = ops.GradSink()
+    ws = [torch.nn.Parameter(torch.zeros(2, 2)) for _ in range(2 * ops.WGRAD_STREAMS + 1)]
+    first = [ops.wgrad_branch_name(sink, [w]) for w in ws]
+    assert len(set(first)) == max(1, ops.WGRAD_STREAMS)                  # taken in turn over all branches
+    again = [ops.wgrad_branch_name(sink, [w]) for w in reversed(ws)][::-1]
+    assert again == first                                                # the same branch on every later launch
+    assert ops.wgrad_branch_name(sink, [ws[3], ws[0]]) == first[3]       # a fused group follows its first member

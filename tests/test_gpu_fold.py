@@ -122,3 +122,56 @@ def test_graphed_step_folds_and_matches_unfolded_steps(prec):
         d = (res[True][j] - res[False][j]).abs()
         assert float(d.max()) < (5e-4 if prec == "fp32" else 1.2e-2), float(d.max())   # bf16: two opposite 5-step walks
         assert float(d.mean()) < (2e-6 if prec == "fp32" else 2e-4), float(d.mean())
+
+
+def test_unfolded_accumulation_keeps_a_parameter_on_one_wgrad_branch(prec, monkeypatch):
+    """A weight-gradient launch is a non-atomic read-modify-write of the flat gradient: the launches of micro-batch i and
+    i+1 for one parameter must be ordered, i.e. issued on the same auxiliary stream (ops.wgrad_branch_name), also with
+    several wgrad branches in use."""
+    from madiff_amd import ops
+    from madiff_amd.trainer import FlatAdamEMA, train_step
+    dev = torch.device("cuda:0")
+    name, n, B = "spread", 2, 4
+    A, Tt, Fd, hh = SHAPES[name]
+    mbs = _micro_batches(name, 5, False, n, B, dev)
+    dr = _draws(n, B, A, Tt, Fd, 20, dev)
+    dif, act = build(name, 32, K=20)
+    opt = FlatAdamEMA(dif, None, lr=1e-3)
+    with_draws = [{**b, **d} for b, d in zip(mbs, dr)]
+    train_step(dif, opt, with_draws, fold=False)            # materialises the flat buffers and the sink
+    seen = {}
+    real = ops.wgrad_branch_name
+
+    def spy(sink, weights):
+        nm = real(sink, weights)
+        seen.setdefault(id(weights[0]), []).append(nm)
+        return nm
+
+    monkeypatch.setattr(ops, "wgrad_branch_name", spy)
+    train_step(dif, opt, with_draws, fold=False)
+    torch.cuda.synchronize()
+    ops.SINK = None
+    assert seen and all(len(v) == n for v in seen.values())              # one launch per micro-batch and layer
+    assert all(len(set(v)) == 1 for v in seen.values())                  # ... always on the parameter's own branch
+    if ops.WGRAD_STREAMS > 1 and ops.WGRAD_SIDE_STREAM:
+        assert len({v[0] for v in seen.values()}) > 1
+
+
+def test_can_fold_checks_every_leaf():
+    """Folding concatenates every leaf: a field that is None in every micro-batch passes through, anything that is not a
+    tensor of one shape sends the step to the unfolded loop (which accepts it)."""
+    from madiff_amd.trainer import can_fold, fold_batches
+    dev = torch.device("cuda:0")
+    dif, act = build("spread", 32, K=20)
+    mbs = _micro_batches("spread", act, False, 2, 4, dev)
+    assert can_fold(dif, mbs)
+    with_none = [{**b, "legal_actions": None, "env_ts": None} for b in mbs]
+    assert can_fold(dif, with_none)
+    big = fold_batches(with_none)
+    assert big["legal_actions"] is None and big["x"].shape[0] == 8
+    loss, _ = dif.loss(**big, micro_batches=2)
+    assert bool(torch.isfinite(loss))
+    assert not can_fold(dif, [{**mbs[0], "legal_actions": None}, {**mbs[1], "legal_actions": torch.ones(4, 24, 3, 5, device=dev)}])
+    assert not can_fold(dif, [{**b, "scale": 1.0} for b in mbs])
+    ragged = [dict(mbs[0]), {**mbs[1], "cond": {"x": mbs[1]["cond"]["x"][:, :-1], "masks": mbs[1]["cond"]["masks"]}}]
+    assert not can_fold(dif, ragged)

@@ -27,6 +27,21 @@ class _Shape:
         self.n_agents, self.horizon, self.history_horizon, self.observation_dim = A, h, hh, F
 
 
+def test_history_is_a_fresh_tensor_per_step_and_needs_reset():
+    """evaluator.py:273-275 builds a new array per environment step (np.stack(list(obs_queue))): a history a caller keeps
+    must not change under it at the next push; and pushing before reset_history says so."""
+    from madiff_amd.planner import DevicePlanner
+    pl = DevicePlanner(_Shape(3, 4, 2, 5), False)
+    with pytest.raises(RuntimeError, match="reset_history"):
+        pl.push_obs(torch.zeros(2, 3, 5))
+    pl.reset_history(torch.zeros(2, 3, 5))
+    h1 = pl.push_obs(torch.full((2, 3, 5), 1.0))
+    kept = h1.clone()
+    h2 = pl.push_obs(torch.full((2, 3, 5), 2.0))
+    assert torch.equal(h1, kept) and h1.data_ptr() != h2.data_ptr()
+    assert torch.equal(h2[:, -1], torch.full((2, 3, 5), 2.0)) and torch.equal(h2[:, -2], torch.full((2, 3, 5), 1.0))
+
+
 @pytest.mark.parametrize("tag", ["cen", "dec", "dec_nohist"])
 def test_planner_calls_sampler_like_reference_evaluator(golden, tag):
     """tests/golden/g10_planner.npz was recorded from the reference's own MADEvaluatorWorker._generate_samples
