@@ -609,6 +609,72 @@ def gen_planner():
     save("g10_planner", **out)
 
 
+# ---------------------------------------------------------------- round 3: full width on the SMAC and ant shapes
+def gen_round3(R):
+    """g11: the shapes BASELINE.json configs[2] / configs[3] name, at the width the benchmarks run (dim 128), from the
+    reference's own classes: `smac` (A=8, T=24, F=88, history 20; d_qk=64 / d_v=256 attention over 8 agents) and `ant`
+    (A=4, T=28, F=54, history 18; levels 28/14/7).  Three parts per the g3g / g4w / g6 fixtures:
+      den.<name>  denoiser forward with dropout + backward: y, input gradient, per-parameter digest + 96 sampled elements
+      loss.smac   GaussianDiffusion.loss + backward, discrete actions (legal-action mask, inv_acc), hidden 256
+      loss.ant    ... continuous actions
+      samp.smac   K=8 guided conditional_sample with closed-form draws
+    Inputs x / gy / returns are closed-form (tests recompute them); recorded draws and outputs are stored."""
+    M = R["ma_temporal"]
+    out = {}
+    B = 2
+    for name in ("smac", "ant"):
+        A, T, Fd, hh = SHAPES[name]
+        net = quiet(M.SharedConvAttentionDeconv, horizon=T, transition_dim=Fd, dim=128, history_horizon=hh,
+                    dim_mults=(1, 4, 8), n_agents=A, returns_condition=True, condition_dropout=0.25)
+        fill_closed_form(net, "model.")
+        x = u(f"g11.{name}.x", (B, T, A, Fd))
+        t = torch.tensor(T_DRAWS[:B])
+        ret = u(f"g11.{name}.ret", (B, 1, A), 0.0, 1.0)
+        with Recorder() as rec:
+            xg = x.clone().requires_grad_(True)
+            y = net(xg, t, returns=ret, use_dropout=True)
+        gy = u(f"g11.{name}.gy", tuple(y.shape))
+        y.backward(gy)
+        named = [(k, p.grad) for k, p in net.named_parameters() if p.grad is not None]
+        names, rows = grad_digest(named)
+        pre = f"den.{name}"
+        out.update({f"{pre}.t": t, f"{pre}.dropout_mask": rec.of("bern")[0], f"{pre}.y_drop": y, f"{pre}.gx": xg.grad,
+                    f"{pre}.gp_names": names, f"{pre}.gp_digest": rows, f"{pre}.gp_samples": grad_samples(named),
+                    f"{pre}.nograd_names": np.array([k for k, p in net.named_parameters() if p.grad is None])})
+        for k in ("self_attn.0.gamma", "self_attn.1.gamma", "self_attn.2.gamma", "net.final_conv.1.bias",
+                  "net.downs.2.1.time_mlp.1.bias", "self_attn.0.value_time_mlp.1.bias"):
+            out[f"{pre}.gp.{k}"] = dict(net.named_parameters())[k].grad
+        del net
+    for name, discrete in (("smac", True), ("ant", False)):
+        dif, (A, T, Fd, hh, act, nact) = build_diffusion(R, name, 128, 200, discrete)
+        vis = np.ones(A, dtype=bool)
+        vis[-1] = False
+        batch = O.synthetic_batch(B, T, A, Fd, act, hh, discrete, nact, seed=17, visible=vis)
+        with Recorder() as rec:
+            loss, info = dif.loss(**batch)
+            loss.backward()
+        named = [(k, p.grad) for k, p in dif.named_parameters() if p.grad is not None]
+        names, rows = grad_digest(named)
+        pre = f"loss.{name}"
+        out.update({f"{pre}.t": rec.of("randint")[0], f"{pre}.noise": rec.of("randn_like")[0],
+                    f"{pre}.dropout_mask": rec.of("bern")[0], f"{pre}.loss": loss.detach(), f"{pre}.visible": vis,
+                    f"{pre}.gp_names": names, f"{pre}.gp_digest": rows, f"{pre}.gp_samples": grad_samples(named)})
+        for k, v in info.items():
+            out[f"{pre}.info.{k}"] = torch.as_tensor(v).detach()
+        del dif
+    name, K, tag = "smac", 8, "g11.samp.smac"
+    dif, (A, T, Fd, hh, act, nact) = build_diffusion(R, name, 128, K)
+    batch = O.synthetic_batch(B, T, A, Fd, act, hh, False, 0, seed=19)
+    cond, returns = batch["cond"], batch["returns"]
+    with Recorder(closed_form_randn=tag) as rec:
+        x, chain = dif.conditional_sample(cond, returns=returns, verbose=False, return_diffusion=True)
+    assert len(rec.of("randn")) == K
+    sel = [1, K // 2]
+    out.update({"samp.smac.x": x, "samp.smac.chain_idx": np.array(sel), "samp.smac.chain": chain[:, sel]})
+    save("g11_w128_smac_ant", **out)
+
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "planner":
         gen_planner()
@@ -620,6 +686,11 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "masks":
         gen_masks()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "round3":      # only the fixture added in round 3
+        torch.manual_seed(1234)
+        torch.set_num_threads(8)
+        gen_round3(load_reference())
         return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":      # only the fixtures added in round 2
         torch.manual_seed(1234)
@@ -642,6 +713,7 @@ def main():
     gen_loss_w128(R)
     gen_env_ts(R)
     gen_alternates(R)
+    gen_round3(R)
 
 
 if __name__ == "__main__":

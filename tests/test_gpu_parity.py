@@ -285,6 +285,109 @@ def test_loss_full_width_vs_reference_golden(golden, prec):
         ops.clear_pack_cache()
 
 
+def U(name, shape, dev, lo=-1.0, hi=1.0):
+    """Closed-form inputs of oracle/gen_golden.py gen_round3 (its u())."""
+    return torch.from_numpy(O.closed_form_uniform("input:" + name, shape, lo, hi).astype(np.float32)).to(dev)
+
+
+@pytest.mark.parametrize("name", ["smac", "ant"])
+def test_denoiser_full_width_smac_ant_vs_reference_golden(golden, prec, name):
+    """dim 128 on the shapes BASELINE.json configs[3] / configs[2] name, against the reference's own classes (round 3:
+    these were compared between the two builds only before).  smac: A = 8 agents -> attn_{fwd,bwd}_v2_kernel<*, 8> at
+    d_qk = 64 / d_v = 256, F = 88 first layer; ant: T = 28 -> levels 28 / 14 / 7 (the 7-row and 14-row all-taps tiles at
+    512 / 1024 channels, partial tiles).  Output, input gradient, every parameter gradient (digest + 96 sampled elements)."""
+    g = golden("g11_w128_smac_ant")
+    dev = torch.device("cuda:0")
+    A, Tt, Fd, hh = SHAPES[name]
+    pre = f"den.{name}"
+    dif, _ = build(name, 128, K=8)
+    net = dif.model
+    x = U(f"g11.{name}.x", (2, Tt, A, Fd), dev)
+    r = U(f"g11.{name}.ret", (2, 1, A), dev, 0.0, 1.0)
+    xg = x.clone().requires_grad_(True)
+    y = net(xg, T(g[pre + ".t"], dev), returns=r, use_dropout=True, dropout_mask=T(g[pre + ".dropout_mask"], dev))
+    err_y = rel_err(y.detach().cpu(), g[pre + ".y_drop"])
+    assert err_y < OUT_TOL[prec], err_y
+    y.backward(U(f"g11.{name}.gy", tuple(y.shape), dev))
+    err_gx = (rel_err if prec == "fp32" else l2_err)(xg.grad.cpu(), g[pre + ".gx"])
+    assert err_gx < (1e-4 if prec == "fp32" else 6e-2), err_gx
+    params = dict(net.named_parameters())
+    for n in g[pre + ".nograd_names"]:
+        assert params[str(n)].grad is None
+    worst_d = digest_check(params, g[pre + ".gp_names"], g[pre + ".gp_digest"], prec)
+    assert worst_d < (1e-3 if prec == "fp32" else 0.1), worst_d
+    worst, who = sampled_gradient_check(params, g[pre + ".gp_names"], g[pre + ".gp_samples"], prec)
+    assert worst < (1e-4 if prec == "fp32" else 0.1), (who, worst)
+    print(f"[{prec} {name}] y {err_y:.2e}  gx {err_gx:.2e}  digest worst {worst_d:.2e}  sampled worst {worst:.2e} ({who})")
+    for k in g:
+        if k.startswith(pre + ".gp."):
+            got = params[k[len(pre) + 4:]].grad.cpu()
+            if got.numel() == 1:
+                continue                         # (the gammas are covered by sampled_gradient_check's scalar rule)
+            assert (rel_err(got, g[k]) < 1e-4) if prec == "fp32" else (l2_err(got, g[k]) < 0.1), k
+
+
+@pytest.mark.parametrize("name,discrete", [("smac", True), ("ant", False)])
+def test_loss_full_width_smac_ant_vs_reference_golden(golden, prec, name, discrete):
+    """GaussianDiffusion.loss + backward at dim 128 / hidden 256: smac = discrete actions (14 logits, legal-action mask,
+    inv_acc), one invisible agent, history 20; ant = continuous actions, history 18."""
+    g = golden("g11_w128_smac_ant")
+    dev = torch.device("cuda:0")
+    pre = f"loss.{name}"
+    A, Tt, Fd, hh = SHAPES[name]
+    dif, act = build(name, 128, 200, discrete)
+    from madiff_amd.host import batch_to_device
+    batch = batch_to_device(O.synthetic_batch(2, Tt, A, Fd, act, hh, discrete, 14 if discrete else 0, seed=17,
+                                              visible=g[pre + ".visible"]), dev)
+    loss, info = dif.loss(**batch, t=T(g[pre + ".t"], dev), noise=T(g[pre + ".noise"], dev),
+                          dropout_mask=T(g[pre + ".dropout_mask"], dev))
+    tol = OUT_TOL[prec]
+    assert loss.dtype == torch.float64
+    assert abs(loss.item() - float(g[pre + ".loss"])) < tol * abs(float(g[pre + ".loss"]))
+    for k in ("a0_loss", "inv_loss", "inv_acc"):
+        if f"{pre}.info.{k}" in g:
+            assert abs(float(info[k]) - float(g[f"{pre}.info.{k}"])) <= tol * abs(float(g[f"{pre}.info.{k}"])) + 1e-9, k
+    assert ("inv_acc" in info) == discrete
+    loss.backward()
+    params = dict(dif.named_parameters())
+    worst_d = digest_check(params, g[pre + ".gp_names"], g[pre + ".gp_digest"], prec)
+    assert worst_d < (1e-3 if prec == "fp32" else 0.1), worst_d
+    worst, who = sampled_gradient_check(params, g[pre + ".gp_names"], g[pre + ".gp_samples"], prec)
+    assert worst < (1e-4 if prec == "fp32" else 0.1), (who, worst)
+    print(f"[{prec} {name}] loss {abs(loss.item() - float(g[pre + '.loss'])) / abs(float(g[pre + '.loss'])):.2e}  "
+          f"digest worst {worst_d:.2e}  sampled worst {worst:.2e} ({who})")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sampling_full_width_smac_vs_reference_golden(golden, use_graph):
+    """K = 8 guided sampling at dim 128 on the SMAC shape (A = 8, history 20), fp32 build, host-supplied noise: <= 1e-3."""
+    from madiff_amd import ops
+    ops.set_precision("fp32")
+    try:
+        g = golden("g11_w128_smac_ant")
+        dev = torch.device("cuda:0")
+        A, Tt, Fd, hh = SHAPES["smac"]
+        K, tag = 8, "g11.samp.smac"
+        dif, act = build("smac", 128, K)
+        batch = O.synthetic_batch(2, Tt, A, Fd, act, hh, False, 0, seed=19)
+        shape = (2, Tt, A, Fd)
+        x_init = 0.5 * T(O.closed_form_normal(f"{tag}.0", shape), dev)
+        z = torch.stack([T(O.closed_form_normal(f"{tag}.{i}", shape)) for i in range(1, K)]).to(dev)
+        cond = {k: v.to(dev) for k, v in batch["cond"].items()}
+        ret = batch["returns"].to(dev)
+        if use_graph:
+            x = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, step_noise=z, use_graph=True)
+        else:
+            x, chain = dif.conditional_sample(cond, returns=ret, verbose=False, return_diffusion=True, x_init=x_init,
+                                              step_noise=z, use_graph=False)
+            assert rel_err(chain[:, g["samp.smac.chain_idx"]].cpu(), g["samp.smac.chain"]) < 1e-3
+        assert rel_err(x.cpu(), g["samp.smac.x"]) < 1e-3
+        m = batch["cond"]["masks"].numpy()
+        assert np.array_equal(x.cpu().numpy()[m], batch["cond"]["x"].numpy()[m])
+    finally:
+        ops.set_precision("bf16")
+
+
 def test_env_ts_condition_vs_reference_golden(golden, prec):
     """env_ts_condition=True (ma_temporal.py:355-362), small width: outputs, input gradient, env_ts_mlp gradients."""
     g = golden("g8_env_ts")

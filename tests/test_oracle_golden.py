@@ -231,3 +231,77 @@ def test_loss_full_width(golden):
     for n, row in zip(g[tag + ".gp_names"], g[tag + ".gp_digest"]):
         gr = pg[str(n)].grad.double()
         assert abs(gr.pow(2).sum().sqrt().item() - row[2]) <= 1e-3 * row[2] + 2e-6, n
+
+
+# ---------------------------------------------------------------- round-3 fixture: full width on the SMAC / ant shapes
+def U(name, shape, lo=-1.0, hi=1.0):
+    """Closed-form inputs of oracle/gen_golden.py gen_round3 (its u())."""
+    return torch.from_numpy(O.closed_form_uniform("input:" + name, shape, lo, hi).astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["smac", "ant"])
+def test_denoiser_full_width_smac_ant(golden, name):
+    """dim 128 on BASELINE configs[3] (A=8, T=24, F=88, d_qk 64 / d_v 256 attention) and configs[2] (A=4, T=28: 28/14/7)."""
+    g = golden("g11_w128_smac_ant")
+    A, Tt, Fd, hh = SHAPES[name]
+    cfg = den_cfg(name, 128)
+    p = {k: O.closed_form_param("model." + k, s).requires_grad_(True) for k, s in O.denoiser_param_shapes(cfg).items()}
+    pre = f"den.{name}"
+    x = U(f"g11.{name}.x", (2, Tt, A, Fd)).requires_grad_(True)
+    r = U(f"g11.{name}.ret", (2, 1, A), 0.0, 1.0)
+    y = O.denoiser_forward(p, cfg, x, T(g[pre + ".t"]), r, T(g[pre + ".dropout_mask"]))
+    assert rel_err(y.detach(), g[pre + ".y_drop"]) < 5e-6
+    y.backward(U(f"g11.{name}.gy", tuple(y.shape)))
+    assert rel_err(x.grad, g[pre + ".gx"]) < 2e-5
+    # key biases have an analytically zero gradient (softmax shift invariance): what both sides hold there is fp32
+    # summation noise, which grows with the agent count -- the absolute floor scales with the largest gradient
+    floor = max(2e-6, 1e-6 * float(g[pre + ".gp_digest"][:, 2].max()))
+    for n, row, smp in zip(g[pre + ".gp_names"], g[pre + ".gp_digest"], g[pre + ".gp_samples"]):
+        gr = p[str(n)].grad
+        assert abs(gr.double().pow(2).sum().sqrt().item() - row[2]) <= 5e-4 * row[2] + floor, n
+        got = gr.reshape(-1)[torch.from_numpy(sample_index(gr.numel()))].numpy()
+        assert np.abs(got - smp).max() <= 2e-4 * np.abs(gr.numpy()).max() + floor, n
+    for n in g[pre + ".nograd_names"]:
+        assert p[str(n)].grad is None
+
+
+@pytest.mark.parametrize("name,discrete", [("smac", True), ("ant", False)])
+def test_loss_full_width_smac_ant(golden, name, discrete):
+    g = golden("g11_w128_smac_ant")
+    pre = f"loss.{name}"
+    A, Tt, Fd, hh = SHAPES[name]
+    dcfg, c = den_cfg(name, 128), dif_cfg(name, 200, discrete=discrete, hidden=256)
+    pg = {k: v.clone().requires_grad_(True) for k, v in full_params(dcfg, c).items()}
+    batch = O.synthetic_batch(2, Tt, A, Fd, c.action_dim, hh, discrete, 14 if discrete else 0, seed=17,
+                              visible=g[pre + ".visible"])
+    loss, info, _ = O.diffusion_loss(pg, dcfg, c, O.DDPMSchedule(200), batch["x"], batch["cond"], batch["loss_masks"],
+                                     T(g[pre + ".t"]), T(g[pre + ".noise"]), batch["returns"], T(g[pre + ".dropout_mask"]),
+                                     legal_actions=batch.get("legal_actions"))
+    assert abs(loss.item() - float(g[pre + ".loss"])) < 5e-6 * abs(float(g[pre + ".loss"]))
+    for k in ("a0_loss", "inv_loss", "inv_acc"):
+        if f"{pre}.info.{k}" in g:
+            assert abs(float(info[k]) - float(g[f"{pre}.info.{k}"])) <= 5e-6 * abs(float(g[f"{pre}.info.{k}"])) + 1e-12, k
+    assert (f"{pre}.info.inv_acc" in g) == discrete
+    loss.backward()
+    floor = max(2e-6, 1e-6 * float(g[pre + ".gp_digest"][:, 2].max()))
+    for n, row in zip(g[pre + ".gp_names"], g[pre + ".gp_digest"]):
+        gr = pg[str(n)].grad.double()
+        assert abs(gr.pow(2).sum().sqrt().item() - row[2]) <= 1e-3 * row[2] + floor, n
+
+
+def test_sampling_full_width_smac(golden):
+    g = golden("g11_w128_smac_ant")
+    A, Tt, Fd, hh = SHAPES["smac"]
+    K, tag = 8, "g11.samp.smac"
+    dcfg, c = den_cfg("smac", 128), dif_cfg("smac", K, hidden=256)
+    p = full_params(dcfg, c)
+    batch = O.synthetic_batch(2, Tt, A, Fd, c.action_dim, hh, False, 0, seed=19)
+    shape = (2, Tt, A, Fd)
+    x_init = 0.5 * T(O.closed_form_normal(f"{tag}.0", shape))
+    z = [T(O.closed_form_normal(f"{tag}.{i}", shape)) for i in range(1, K)]
+    with torch.no_grad():
+        x, chain = O.conditional_sample(p, dcfg, c, O.DDPMSchedule(K), batch["cond"], batch["returns"], x_init, z, True)
+    assert rel_err(chain[:, g["samp.smac.chain_idx"]], g["samp.smac.chain"]) < 1e-4
+    assert rel_err(x, g["samp.smac.x"]) < 1e-4
+    m = batch["cond"]["masks"].numpy()
+    assert np.array_equal(x.numpy()[m], batch["cond"]["x"].numpy()[m])
