@@ -179,7 +179,12 @@ int madiff_gn_mish_bwd(int dtype, const void* y, int ldy, const void* dout, int 
                        float* drowbias, int ldrb, int N, int T, int C, int Cpad, int G, madiff_stream_t stream);
 
 /* Cross-agent attention core on the fused projection matrix qkv = [q | k | v] ([M, 2*Cq + C]):
- * softmax_a2(q.k / sqrt(d_qk*T)) . v, then x + gamma*out.  Replaces temporal.py:104-124. */
+ * softmax_a2(q.k / sqrt(d_qk*T)) . v, then x + gamma*out.  Replaces temporal.py:104-124.
+ * bf16 build, A <= 8, head slices a multiple of 32 features (dim 128: d_qk 64 / 32, d_v 256 / 128): the contractions over
+ * the (d, t) feature axis -- q.k^T, and dO.v^T in backward -- run on v_mfma_f32_16x16x32_bf16 with 16 / {4, 8} batch
+ * elements packed into the 16 rows of a tile, operands loaded straight from global memory in the MFMA fragment layout;
+ * madiff_attn_mfma_covers() tells whether a shape takes that form (1) or the VALU kernels (0). */
+int madiff_attn_mfma_covers(int dtype, int A, int T, int H, int Cq, int C);
 int madiff_attn_fwd(int dtype, const void* qkv, int ldq, const void* x, int ldx, void* out, int ldo, const float* gamma,
                     int B, int A, int T, int H, int Cq, int C, int residual, madiff_stream_t stream);
 int madiff_attn_bwd(int dtype, const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg, const float* gamma,
@@ -209,6 +214,14 @@ int madiff_unpack_output(int dtype, const void* in, int ld, float* out, int B, i
 int madiff_posterior_step(const float* x, const float* eps_c, const float* eps_u, float w, const float* z, const float* cond,
                           const uint8_t* mask, const float* coef, const int* step_ptr, int step_val, float* out, long total,
                           madiff_stream_t stream);
+/* madiff_posterior_step with the scheduler's noise taken on the device -- diffusers' `randn_tensor` inside
+ * DDPMScheduler.step (diffusion.py:261) -- so that the whole K-step loop (diffusion.py:249-263) is device-driven and can be
+ * ONE hipGraph launch.  z_all: explicit draws [n_steps, total] (row = step index; parity runs with host-supplied noise) or
+ * NULL; rng: device uint64[2] = {seed, stream id} for z ~ N(0,1) from Philox4x32-10 + Box-Muller, counter = (element
+ * index / 4, step index, stream id): every (seed, step, element) has its own draw, independent of the launch geometry. */
+int madiff_posterior_step_rng(const float* x, const float* eps_c, const float* eps_u, float w, const float* z_all,
+                              const unsigned long long* rng, const float* cond, const uint8_t* mask, const float* coef,
+                              const int* step_ptr, int step_val, float* out, long total, madiff_stream_t stream);
 int madiff_inpaint(float* x, const float* cond, const uint8_t* mask, long total, madiff_stream_t stream);
 /* The SMAC data encoders (utils/data_encoder.py:11-20), applied where the reference calls self.data_encoder
  * (diffusion.py:252,269,294): x[b, t >= 1, a, f < k] = x[b, 0, a, f], in place on a [B,T,A,F] fp32 trajectory. */

@@ -5,6 +5,7 @@
 // (A <= 16) are far below an MFMA tile, so this stage is bandwidth/latency-bound by design: it reads
 // q, k, v, x once and writes out once.
 #include "common.h"
+#include <stdlib.h>
 
 #define ATT_MAX_ENT 1024   // H * A * A
 
@@ -136,6 +137,12 @@ extern "C" int madiff_attn_bwd_v2(int dtype, const void* qkv, int ldq, const voi
                                   int residual, float* drb, int ldrb, hipStream_t stream);
 extern "C" int madiff_seqsum(int dtype, const void* x, int ld, float* out, int ldo, long N, int T, int C, hipStream_t stream);
 
+static int att3_fwd(const void* qkv, int ldq, const void* x, int ldx, void* out, int ldo, const float* gamma, int B, int A, int T,
+                    int H, int Cq, int C, float scale, int residual, hipStream_t stream);
+static int att3_bwd(const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg, const float* gamma, float* dgamma,
+                    int B, int A, int T, int H, int Cq, int C, float scale, int residual, float* drb, int ldrb,
+                    hipStream_t stream);
+
 static int att_check(int B, int A, int T, int H, int Cq, int C) {
   return (B > 0 && A > 0 && T > 0 && H > 0 && Cq > 0 && C > 0 && Cq % H == 0 && C % H == 0 &&
           H * A * A <= ATT_MAX_ENT) ? 0 : -1;
@@ -146,6 +153,10 @@ extern "C" int madiff_attn_fwd(int dtype, const void* qkv, int ldq, const void* 
                                hipStream_t stream) {
   if (att_check(B, A, T, H, Cq, C) || ldq < 2 * Cq + C || ldx < C || ldo < C || (residual && !gamma)) return -1;
   float scale = 1.0f / sqrtf((float)(Cq / H) * (float)T);
+  if (dtype == MADIFF_BF16) {          // the feature-axis contractions on MFMA (v3), where the shape allows
+    int rc = att3_fwd(qkv, ldq, x, ldx, out, ldo, gamma, B, A, T, H, Cq, C, scale, residual, stream);
+    if (rc <= 0) return rc;
+  }
   {
     int rc = madiff_attn_fwd_v2(dtype, qkv, ldq, x, ldx, out, ldo, gamma, B, A, T, H, Cq, C, scale, residual, stream);
     if (rc <= 0) return rc;
@@ -182,6 +193,10 @@ extern "C" int madiff_attn_bwd_rb(int dtype, const void* qkv, int ldq, const voi
       (drowbias && ldrb < 2 * Cq + C))
     return -1;
   float scale = 1.0f / sqrtf((float)(Cq / H) * (float)T);
+  if (dtype == MADIFF_BF16) {
+    int rc = att3_bwd(qkv, ldq, dout, ldd, dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual, drowbias, ldrb, stream);
+    if (rc <= 0) return rc;
+  }
   {
     int rc = madiff_attn_bwd_v2(dtype, qkv, ldq, dout, ldd, dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual,
                                 drowbias, ldrb, stream);
@@ -500,5 +515,341 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_attn_bwd_v2(int dtyp
   if (dtype == MADIFF_BF16) { if (A <= 4) ATT2_BWD(bf16_t, 4); else ATT2_BWD(bf16_t, 8); }
   else { if (A <= 4) ATT2_BWD(float, 4); else ATT2_BWD(float, 8); }
 #undef ATT2_BWD
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ================================================================================================
+// v3 (bf16 build): the contractions over the (d, t) feature axis on MFMA.
+//
+// Reference: temporal.py:104-122.  Per (batch element, head) the layer is two kinds of products: the A x A score-shaped
+// ones that contract over the FEATURES of a head (S = Q K^T over T*d_qk features, and in backward dP = dO V^T over T*d_v),
+// and the mixes of A rows with A x A weights (P V, P^T dO, dS K, dS^T Q: K dimension = A <= 8).  The first kind is where the
+// MACs per loaded byte are and it maps onto v_mfma_f32_16x16x32_bf16 with no LDS staging at all: 16 / AP batch elements
+// (AP = A padded to 4 or 8) are packed into the 16 rows of one MFMA tile, packed row rho = (b', a); a lane's A- and
+// B-operand fragment is 8 consecutive features of ITS packed row, i.e. one 16-byte global load each, straight into the
+// MFMA operand registers.  The 16 x 16 result holds the A x A blocks of the packed batch elements on its diagonal (the
+// off-diagonal cross-batch products are ignored: with A = 4 that is 4x redundant MFMA work on a kernel that is bound by
+// its memory traffic).  The K-steps of a head are dealt out over the 8 waves of the workgroup and the partial tiles meet
+// in LDS.  The second kind (K = A) stays on the VALU: an MFMA would multiply zeros for >= half of its K.
+//
+// Against v2 (one workgroup per (b, h), q/k staged in LDS as fp32, scores by wave_sum loops) this form has every global
+// load of a phase in flight at once and 4 (A <= 4) or 2 (A <= 8) batch elements per workgroup.  The row-bias gradient
+// (sum over t of dqkv, temporal.py:100-111's time conditioning) is accumulated with LDS atomics while dqkv is produced.
+// Needs d_qk % 32 == 0 and d_v % 32 == 0 (dim 128: 64 / 256 and 32 / 128); other shapes and the fp32 build use v2.
+// ================================================================================================
+template <int AP>
+__device__ __forceinline__ void att3_softmax_row(const float* s, int A, float* p) {
+  float mx = s[0];
+#pragma unroll
+  for (int j = 1; j < AP; j++) if (j < A) mx = fmaxf(mx, s[j]);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < AP; j++) if (j < A) { p[j] = __expf(s[j] - mx); sum += p[j]; }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int j = 0; j < AP; j++) p[j] = j < A ? p[j] * inv : 0.f;
+}
+
+// acc += X[rho1] . Y[rho2] over the wave's share of the K-steps: K-step s = (t, 32-feature block j) of a head slice that is
+// `dh` features wide; xrow / yrow = this lane's packed row at feature offset fq * 8 of the slice (t = 0)
+template <int NW>
+__device__ __forceinline__ f32x4 att3_rowdots(const bf16_t* __restrict__ xrow, int ldx, const bf16_t* __restrict__ yrow, int ldy,
+                                              int Tn, int dh, int wave) {
+  const int spt = dh >> 5, nks = Tn * spt;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // four K-steps per round: their eight 16-byte loads are issued together, then the MFMAs (a round's tail steps beyond the
+  // slice re-read the last step and are skipped by a wave-uniform branch)
+  for (int s0 = wave; s0 < nks; s0 += 4 * NW) {
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int s = min(s0 + u * NW, nks - 1);
+      const int t = s / spt, j = s - t * spt;
+      a[u] = *(const bf16x8*)(xrow + (size_t)t * ldx + j * 32);
+      b[u] = *(const bf16x8*)(yrow + (size_t)t * ldy + j * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (s0 + u * NW < nks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int AP, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, int ldq,
+                                                                const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ out,
+                                                                int ldo, const float* __restrict__ gamma_p, int B, int A, int Tn,
+                                                                int H, int Cq, int C, float scale, int residual) {
+  constexpr int G = 16 / AP, NT = NW * 64;
+  __shared__ float Sp[NW][256];
+  __shared__ float Ps[16 * AP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int dqk = Cq / H, dv = C / H;
+  const int bg = blockIdx.x / H, h = blockIdx.x - bg * H, b0 = bg * G;
+  const float gamma = residual ? gamma_p[0] : 1.f;
+  // ---- first vector of the P.V pass: its V rows are requested before the score phase (nothing below depends on them)
+  const int vpr = dv >> 3, nv = G * Tn * vpr;
+  bf16x8 vfirst[AP];
+  {
+    const int cv = tid % vpr, r = tid / vpr, t = r % Tn, pb = r / Tn;
+    if (tid < nv && b0 + pb < B) {
+#pragma unroll
+      for (int a2 = 0; a2 < AP; a2++)
+        if (a2 < A) vfirst[a2] = *(const bf16x8*)(qkv + ((size_t)((b0 + pb) * A + a2) * Tn + t) * ldq + 2 * Cq + h * dv + cv * 8);
+    }
+  }
+  // ---- scores on MFMA: packed row fr = (b', a); rows beyond the problem read a valid row and are never used
+  {
+    const int pb = fr / AP, pa = fr - pb * AP;
+    const int rb = (pa < A && b0 + pb < B) ? (b0 + pb) * A + pa : b0 * A;
+    const bf16_t* qrow = qkv + (size_t)rb * Tn * ldq + h * dqk + fq * 8;
+    const f32x4 acc = att3_rowdots<NW>(qrow, ldq, qrow + Cq, ldq, Tn, dqk, wave);
+#pragma unroll
+    for (int r = 0; r < 4; r++) Sp[wave][(fq * 4 + r) * 16 + fr] = acc[r];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int pb = tid / AP, a1 = tid - pb * AP;
+    float s[AP], p[AP];
+#pragma unroll
+    for (int j = 0; j < AP; j++) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) v += Sp[w][tid * 16 + pb * AP + j];
+      s[j] = v * scale;
+    }
+    att3_softmax_row<AP>(s, A, p);
+#pragma unroll
+    for (int j = 0; j < AP; j++) Ps[tid * AP + j] = a1 < A ? p[j] : 0.f;
+  }
+  __syncthreads();
+  // ---- out[a1] = x[a1] + gamma * sum_a2 P[a1][a2] v[a2] on 8-feature vectors
+  for (int i = tid; i < nv; i += NT) {
+    const int cv = i % vpr, r = i / vpr, t = r % Tn, pb = r / Tn;
+    const int b = b0 + pb;
+    if (b >= B) continue;
+    const int c = h * dv + cv * 8;
+    bf16x8 v[AP], xv[AP];
+#pragma unroll
+    for (int a = 0; a < AP; a++)
+      if (a < A) {
+        const size_t row = (size_t)(b * A + a) * Tn + t;
+        v[a] = i == tid ? vfirst[a] : *(const bf16x8*)(qkv + row * ldq + 2 * Cq + c);
+        if (residual) xv[a] = *(const bf16x8*)(x + row * ldx + c);
+      }
+#pragma unroll
+    for (int a1 = 0; a1 < AP; a1++) {
+      if (a1 >= A) continue;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = 0.f;
+#pragma unroll
+      for (int a2 = 0; a2 < AP; a2++)
+        if (a2 < A) {
+          const float p = Ps[(pb * AP + a1) * AP + a2];
+#pragma unroll
+          for (int e = 0; e < 8; e++) o[e] += p * (float)v[a2][e];
+        }
+      bf16x8 ov;
+#pragma unroll
+      for (int e = 0; e < 8; e++) ov[e] = (bf16_t)(residual ? (float)xv[a1][e] + gamma * o[e] : o[e]);
+      *(bf16x8*)(out + ((size_t)(b * A + a1) * Tn + t) * ldo + c) = ov;
+    }
+  }
+}
+
+template <int AP, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, int ldq,
+                                                                const bf16_t* __restrict__ dout, int ldd,
+                                                                bf16_t* __restrict__ dqkv, int ldg, const float* __restrict__ gamma_p,
+                                                                float* __restrict__ dgamma, int B, int A, int Tn, int H, int Cq,
+                                                                int C, float scale, int residual, float* __restrict__ drb, int ldrb) {
+  constexpr int G = 16 / AP, NT = NW * 64;
+  __shared__ float Sp[NW][256];
+  __shared__ float Dp[NW][256];
+  __shared__ float Ps[16 * AP];
+  __shared__ float Ds[16 * AP];
+  extern __shared__ float Rs[];            // [16][W] sums over t of the dqkv tile (only with drb)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int dqk = Cq / H, dv = C / H, W = 2 * dqk + dv;
+  const int bg = blockIdx.x / H, h = blockIdx.x - bg * H, b0 = bg * G;
+  const float gamma = residual ? gamma_p[0] : 1.f;
+  if (drb)
+    for (int i = tid; i < 16 * W; i += NT) Rs[i] = 0.f;
+  // ---- S = Q K^T and raw dP = dO V^T on MFMA (packed rows, operands straight from global memory)
+  {
+    const int pb = fr / AP, pa = fr - pb * AP;
+    const int rb = (pa < A && b0 + pb < B) ? (b0 + pb) * A + pa : b0 * A;
+    const bf16_t* qrow = qkv + (size_t)rb * Tn * ldq + h * dqk + fq * 8;
+    const bf16_t* vrow = qkv + (size_t)rb * Tn * ldq + 2 * Cq + h * dv + fq * 8;
+    const bf16_t* grow = dout + (size_t)rb * Tn * ldd + h * dv + fq * 8;
+    const f32x4 accd = att3_rowdots<NW>(grow, ldd, vrow, ldq, Tn, dv, wave);
+    const f32x4 accs = att3_rowdots<NW>(qrow, ldq, qrow + Cq, ldq, Tn, dqk, wave);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      Sp[wave][(fq * 4 + r) * 16 + fr] = accs[r];
+      Dp[wave][(fq * 4 + r) * 16 + fr] = accd[r];
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {       // packed row (b', a1): softmax, its backward -> dS (times scale), and the row's share of dgamma
+    const int pb = tid / AP, a1 = tid - pb * AP;
+    const bool valid = a1 < A && b0 + pb < B;
+    float s[AP], p[AP], d[AP];
+#pragma unroll
+    for (int j = 0; j < AP; j++) {
+      float v = 0.f, u = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) { v += Sp[w][tid * 16 + pb * AP + j]; u += Dp[w][tid * 16 + pb * AP + j]; }
+      s[j] = v * scale;
+      d[j] = u;
+    }
+    att3_softmax_row<AP>(s, A, p);
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < AP; j++) if (j < A) dot += p[j] * d[j];
+#pragma unroll
+    for (int j = 0; j < AP; j++) {
+      Ps[tid * AP + j] = valid ? p[j] : 0.f;
+      Ds[tid * AP + j] = (valid && j < A) ? p[j] * gamma * (d[j] - dot) * scale : 0.f;
+    }
+    if (!valid) dot = 0.f;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (tid == 0 && residual) atomicAdd(dgamma, dot);
+  }
+  __syncthreads();
+  // ---- the K = A mixes on 8-feature vectors, one index space over both kinds so every thread has work:
+  //   [0, nvv): dv[a2] = gamma * sum_a1 P[a1][a2] dO[a1]        [nvv, nvv + nvq): dq[a1] = sum_a2 dS[a1][a2] k[a2],
+  //                                                                                dk[a2] = sum_a1 dS[a1][a2] q[a1]
+  const int vprv = dv >> 3, nvv = G * Tn * vprv, vprq = dqk >> 3, nvq = G * Tn * vprq;
+  for (int i = tid; i < nvv + nvq; i += NT) {
+    if (i < nvv) {
+      const int cv = i % vprv, r = i / vprv, t = r % Tn, pb = r / Tn;
+      const int b = b0 + pb;
+      if (b >= B) continue;
+      const int c = h * dv + cv * 8;
+      bf16x8 g[AP];
+#pragma unroll
+      for (int a = 0; a < AP; a++)
+        if (a < A) g[a] = *(const bf16x8*)(dout + ((size_t)(b * A + a) * Tn + t) * ldd + c);
+#pragma unroll
+      for (int a2 = 0; a2 < AP; a2++) {
+        if (a2 >= A) continue;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = 0.f;
+#pragma unroll
+        for (int a1 = 0; a1 < AP; a1++)
+          if (a1 < A) {
+            const float p = Ps[(pb * AP + a1) * AP + a2];
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] += p * (float)g[a1][e];
+          }
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { o[e] *= gamma; ov[e] = (bf16_t)o[e]; }
+        *(bf16x8*)(dqkv + ((size_t)(b * A + a2) * Tn + t) * ldg + 2 * Cq + c) = ov;
+        if (drb) {
+          float* rs = Rs + (pb * AP + a2) * W + 2 * dqk + cv * 8;
+#pragma unroll
+          for (int e = 0; e < 8; e++) atomicAdd(rs + e, o[e]);
+        }
+      }
+    } else {
+      const int j = i - nvv;
+      const int cv = j % vprq, r = j / vprq, t = r % Tn, pb = r / Tn;
+      const int b = b0 + pb;
+      if (b >= B) continue;
+      const int c = h * dqk + cv * 8;
+      // two sub-passes (dq from the K rows, then dk from the Q rows): half the live registers of doing both at once
+#pragma unroll
+      for (int part = 0; part < 2; part++) {
+        bf16x8 rw[AP];
+#pragma unroll
+        for (int a = 0; a < AP; a++)
+          if (a < A) rw[a] = *(const bf16x8*)(qkv + ((size_t)(b * A + a) * Tn + t) * ldq + c + (part == 0 ? Cq : 0));
+#pragma unroll
+        for (int a = 0; a < AP; a++) {
+          if (a >= A) continue;
+          float ov[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) ov[e] = 0.f;
+#pragma unroll
+          for (int o = 0; o < AP; o++)
+            if (o < A) {
+              const float w = part == 0 ? Ds[(pb * AP + a) * AP + o] : Ds[(pb * AP + o) * AP + a];
+#pragma unroll
+              for (int e = 0; e < 8; e++) ov[e] += w * (float)rw[o][e];
+            }
+          bf16x8 vv;
+#pragma unroll
+          for (int e = 0; e < 8; e++) vv[e] = (bf16_t)ov[e];
+          *(bf16x8*)(dqkv + ((size_t)(b * A + a) * Tn + t) * ldg + c + (part == 0 ? 0 : Cq)) = vv;
+          if (drb) {
+            float* rs = Rs + (pb * AP + a) * W + (part == 0 ? 0 : dqk) + cv * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) atomicAdd(rs + e, ov[e]);
+          }
+        }
+      }
+    }
+  }
+  if (drb) {
+    __syncthreads();
+    for (int i = tid; i < 16 * W; i += NT) {
+      const int rho = i / W, c = i - rho * W;
+      const int pb = rho / AP, a = rho - pb * AP;
+      if (a >= A || b0 + pb >= B) continue;
+      const int col = c < dqk ? h * dqk + c : (c < 2 * dqk ? Cq + h * dqk + (c - dqk) : 2 * Cq + h * dv + (c - 2 * dqk));
+      drb[(size_t)((b0 + pb) * A + a) * ldrb + col] = Rs[i];
+    }
+  }
+}
+
+static int att3_on() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MADIFF_ATTN_MFMA"); v = e ? (atoi(e) != 0) : 1; }
+  return v;
+}
+
+// 1 when the MFMA form covers the layer (bf16, A <= 8, head slices a multiple of 32 features, 16-byte aligned rows)
+extern "C" int madiff_attn_mfma_covers(int dtype, int A, int T, int H, int Cq, int C) {
+  if (dtype != MADIFF_BF16 || !att3_on() || att_check(1, A, T, H, Cq, C)) return 0;
+  return (A <= 8 && (Cq / H) % 32 == 0 && (C / H) % 32 == 0) ? 1 : 0;
+}
+
+static int att3_aligned(const void* p1, int ld1, const void* p2, int ld2, const void* p3, int ld3) {
+  return ld1 % 8 == 0 && ld2 % 8 == 0 && ld3 % 8 == 0 && ((size_t)p1 % 16) == 0 && ((size_t)p2 % 16) == 0 && ((size_t)p3 % 16) == 0;
+}
+
+static int att3_fwd(const void* qkv, int ldq, const void* x, int ldx, void* out, int ldo, const float* gamma, int B, int A, int T,
+                    int H, int Cq, int C, float scale, int residual, hipStream_t stream) {
+  if (!madiff_attn_mfma_covers(MADIFF_BF16, A, T, H, Cq, C) || !att3_aligned(qkv, ldq, x, ldx, out, ldo) || Cq % 8) return 1;
+  const int AP = A <= 4 ? 4 : 8, G = 16 / AP;
+  const dim3 grid(((B + G - 1) / G) * H);
+  if (AP == 4)
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<4, 8>), grid, dim3(512), 0, stream, (const bf16_t*)qkv, ldq, (const bf16_t*)x, ldx,
+                       (bf16_t*)out, ldo, gamma, B, A, T, H, Cq, C, scale, residual);
+  else
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<8, 8>), grid, dim3(512), 0, stream, (const bf16_t*)qkv, ldq, (const bf16_t*)x, ldx,
+                       (bf16_t*)out, ldo, gamma, B, A, T, H, Cq, C, scale, residual);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+static int att3_bwd(const void* qkv, int ldq, const void* dout, int ldd, void* dqkv, int ldg, const float* gamma, float* dgamma,
+                    int B, int A, int T, int H, int Cq, int C, float scale, int residual, float* drb, int ldrb,
+                    hipStream_t stream) {
+  if (!madiff_attn_mfma_covers(MADIFF_BF16, A, T, H, Cq, C) || !att3_aligned(qkv, ldq, dout, ldd, dqkv, ldg) || Cq % 8) return 1;
+  const int AP = A <= 4 ? 4 : 8, G = 16 / AP;
+  const size_t sh = drb ? (size_t)16 * (2 * (Cq / H) + C / H) * sizeof(float) : 0;
+  if (sh > 40 * 1024) return 1;
+  const dim3 grid(((B + G - 1) / G) * H);
+  if (AP == 4)
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<4, 8>), grid, dim3(512), sh, stream, (const bf16_t*)qkv, ldq, (const bf16_t*)dout,
+                       ldd, (bf16_t*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual, drb, ldrb);
+  else
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<8, 8>), grid, dim3(512), sh, stream, (const bf16_t*)qkv, ldq, (const bf16_t*)dout,
+                       ldd, (bf16_t*)dqkv, ldg, gamma, dgamma, B, A, T, H, Cq, C, scale, residual, drb, ldrb);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

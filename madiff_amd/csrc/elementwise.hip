@@ -77,6 +77,73 @@ __global__ void posterior_step_kernel(const float* __restrict__ x, const float* 
   }
 }
 
+// ---- the same step with the noise produced ON THE DEVICE (or read from a per-step table), for the whole-loop graph:
+// nothing between two denoising steps needs the host.  z_all != null: explicit draws, row `i` of a [n_steps, total] table
+// (parity runs: host-supplied noise).  z_all == null: z ~ N(0, 1) from Philox4x32-10 (Salmon et al., SC'11; the generator
+// torch / cuRAND / rocRAND use) keyed by rng[0] (64-bit seed), counter = (element index / 4, step index i, rng[1]) -- one
+// Philox block yields four 32-bit words = two Box-Muller pairs = the draws of four consecutive elements, so every
+// (seed, step, element) has its own draw whatever the launch geometry.  tests/test_gpu_kernels.py restates the generator
+// in numpy and compares word for word.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&r)[4]) {
+#pragma unroll
+  for (int round = 0; round < 10; round++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1,
+                   n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+// two standard normals from two 32-bit words: u1 in (0, 1], u2 in [0, 1)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+  const float rad = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.28318530717958647692f * u2, &sn, &cs);
+  n0 = rad * cs;
+  n1 = rad * sn;
+}
+
+__global__ void posterior_step_rng_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
+                                          const float* __restrict__ eps_u, float w, const float* __restrict__ z_all,
+                                          const unsigned long long* __restrict__ rng, const float* __restrict__ cond,
+                                          const uint8_t* __restrict__ mask, const float* __restrict__ coef,
+                                          const int* __restrict__ step_ptr, int step_val, float* __restrict__ out, long total) {
+  const int i = step_ptr ? step_ptr[0] : step_val;
+  const float sb = coef[i * 6 + 0], isa = coef[i * 6 + 1], c0 = coef[i * 6 + 2], ct = coef[i * 6 + 3],
+              ce = coef[i * 6 + 4], sg = coef[i * 6 + 5];
+  const float* z = z_all ? z_all + (size_t)i * total : nullptr;
+  const uint32_t k0 = rng ? (uint32_t)rng[0] : 0u, k1 = rng ? (uint32_t)(rng[0] >> 32) : 0u;
+  const uint32_t c3 = rng ? (uint32_t)rng[1] : 0u;
+  const long quads = (total + 3) >> 2;
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < quads; q += (long)gridDim.x * blockDim.x) {
+    float zn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sg != 0.f && !z) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)q, (uint32_t)((unsigned long long)q >> 32), (uint32_t)i, c3, k0, k1, r);
+      box_muller(r[0], r[1], zn[0], zn[1]);
+      box_muller(r[2], r[3], zn[2], zn[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const long e = q * 4 + j;
+      if (e >= total) break;
+      const float xv = x[e], ec = eps_c[e];
+      const float ep = eps_u ? (eps_u[e] + w * (ec - eps_u[e])) : ec;
+      float x0 = (xv - sb * ep) * isa;
+      x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      float v = c0 * x0 + ct * xv + ce * ep;
+      if (sg != 0.f) v += sg * (z ? z[e] : zn[j]);
+      if (mask && mask[e]) v = cond[e];
+      out[e] = v;
+    }
+  }
+}
+
 __global__ void inpaint_kernel(float* __restrict__ x, const float* __restrict__ cond, const uint8_t* __restrict__ mask,
                                long total) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
@@ -364,6 +431,22 @@ extern "C" int madiff_posterior_step(const float* x, const float* eps_c, const f
   if (!x || !eps_c || !coef || !out || (mask && !cond) || (!step_ptr && step_val < 0)) return -1;
   hipLaunchKernelGGL(posterior_step_kernel, dim3(nblocks(total)), dim3(256), 0, stream, x, eps_c, eps_u, w, z, cond, mask,
                      coef, step_ptr, step_val, out, total);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
+// The posterior step with device-side noise (see posterior_step_rng_kernel): z_all = [n_steps, total] explicit draws (row =
+// the step index) or NULL; rng = device {seed, stream id} (uint64[2]) for the Philox draw when z_all is NULL (one of the two
+// must be given unless every sigma of the coefficient table is 0: DDIM).  Replaces diffusers' `randn_tensor` inside
+// DDPMScheduler.step (called at diffusion.py:261), so the K-step loop needs no host work between steps.
+extern "C" int madiff_posterior_step_rng(const float* x, const float* eps_c, const float* eps_u, float w, const float* z_all,
+                                         const unsigned long long* rng, const float* cond, const uint8_t* mask,
+                                         const float* coef, const int* step_ptr, int step_val, float* out, long total,
+                                         hipStream_t stream) {
+  if (total <= 0) return 0;
+  if (!x || !eps_c || !coef || !out || (mask && !cond) || (!step_ptr && step_val < 0)) return -1;
+  hipLaunchKernelGGL(posterior_step_rng_kernel, dim3(nblocks((total + 3) / 4)), dim3(256), 0, stream, x, eps_c, eps_u, w, z_all,
+                     rng, cond, mask, coef, step_ptr, step_val, out, total);
   MADIFF_CHECK_LAUNCH();
   return 0;
 }

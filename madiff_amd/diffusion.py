@@ -6,9 +6,9 @@ Differences that are additions, not changes of behaviour:
 * every random draw of the reference may be supplied explicitly (``t``, ``noise``, ``dropout_mask`` to
   ``loss``; ``x_init``/``step_noise`` to ``conditional_sample``) so results can be compared bit-for-bit in
   draw order with the reference; without them torch's RNG is used in the reference's draw order;
-* the K-step loop can be captured into ONE hipGraph step that is replayed K times with a device-side step
-  counter (``use_graph=True``, the default on a GPU): inpaint -> one 2B-batch guided forward -> fused
-  posterior step;
+* the whole K-step loop is captured into ONE hipGraph (``use_graph=True``, the default on a GPU): K x [inpaint ->
+  one 2B-batch guided forward -> fused posterior step], driven by a device-side step counter, the scheduler's
+  noise drawn on the device (Philox) or read from a host-supplied table -- one host launch per call;
 * the classifier-free-guidance pair runs as one 2B batch.
 """
 from __future__ import annotations
@@ -222,8 +222,9 @@ class GaussianDiffusion(nn.Module):
         return self.model(x, t, env_timestep=env_ts, attention_masks=attention_masks)
 
     def _denoise_step(self, st, returns, env_ts, bsz, t_len):
-        """One loop iteration on persistent buffers (graph-capturable): eps from x (already inpainted), then the
-        fused posterior step + inpainting writes the next x in place."""
+        """One loop iteration on persistent buffers (graph-capturable, device-driven: the step index lives in st["state"]):
+        eps from x (already inpainted), then the fused posterior step -- guidance blend, x0, clip, mean, + sigma z with z
+        read from the step's row of st["z_all"] or drawn on the device (Philox), inpainting -- writes the next x in place."""
         x = st["x"]
         lib = ops.lib
         lib.call("madiff_sampler_fill_time", st["state"].data_ptr(), st["tsteps"].data_ptr(), st["ts"].data_ptr(), bsz,
@@ -244,10 +245,20 @@ class GaussianDiffusion(nn.Module):
                             force_dropout=True)
         else:
             ec, eu = self.model(x, st["ts"], env_timestep=env_ts, attention_masks=None), None
-        z = st["z"]
-        ops.posterior_step(x, ec.contiguous(), None if eu is None else eu.contiguous(), self.condition_guidance_w, z,
-                           st["cond_x"], st["mask"], st["coef"], x, step_ptr=st["state"])
+        ops.posterior_step_rng(x, ec.contiguous(), None if eu is None else eu.contiguous(), self.condition_guidance_w,
+                               st["z_all"], st["rng"] if st["z_all"] is None else None, st["cond_x"], st["mask"], st["coef"], x,
+                               step_ptr=st["state"])
         lib.call("madiff_sampler_advance", st["state"].data_ptr(), ops._stream())
+
+    @staticmethod
+    def _graph_chunk(n_steps: int) -> int:
+        """Denoising steps held by ONE captured graph.  Default: all of them -- the K-step loop is one graph launch
+        (diffusion.py:249-263 without the host between steps).  MADIFF_SAMPLE_GRAPH_STEPS=<n> caps it (the graph then holds
+        the largest divisor of K below the cap and is replayed K / chunk times; 1 = round 2's one-step graph)."""
+        cap = int(os.environ.get("MADIFF_SAMPLE_GRAPH_STEPS", "0"))
+        if cap <= 0 or cap >= n_steps:
+            return n_steps
+        return max(d for d in range(1, cap + 1) if n_steps % d == 0)
 
     @torch.no_grad()
     def conditional_sample(self, cond: Dict[str, torch.Tensor], returns: Optional[torch.Tensor] = None,
@@ -256,7 +267,10 @@ class GaussianDiffusion(nn.Module):
                            return_diffusion: bool = False, x_init: Optional[torch.Tensor] = None,
                            step_noise: Optional[torch.Tensor] = None, use_graph: Optional[bool] = None):
         """diffusion.py:214-275.  ``x_init`` = the tempered initial draw (0.5*randn); ``step_noise`` [n_steps, B,T,A,F]
-        = the N(0,1) draws of the scheduler steps (row i is consumed by loop iteration i)."""
+        = the N(0,1) draws of the scheduler steps (row i is consumed by loop iteration i).  Without ``step_noise`` the
+        scheduler's draws are made on the device (Philox4x32-10 keyed by a seed taken from torch's device generator, so
+        ``torch.manual_seed`` fixes them; eager and graph runs of one seed give the same trajectories).
+        On a GPU the whole K-step loop is ONE hipGraph launch (``use_graph``, default unless ``return_diffusion``)."""
         batch_size = cond["x"].shape[0]
         t_len = horizon or self.horizon + self.history_horizon
         shape = (batch_size, t_len, self.n_agents, self.observation_dim)
@@ -268,70 +282,84 @@ class GaussianDiffusion(nn.Module):
             use_graph = not return_diffusion
 
         needs_z = not self.use_ddim_sample
+        explicit = needs_z and step_noise is not None
         x0 = (0.5 * torch.randn(shape, device=device)) if x_init is None else x_init.to(device, torch.float32)
         if returns is not None:
             returns = returns.to(device, torch.float32).contiguous()
+        # {seed, stream id} of the device-side draws: two words from torch's DEVICE generator (where the reference's
+        # scheduler draws its noise too), made outside any graph
+        rng_host = (torch.randint(0, 2 ** 62, (2,), dtype=torch.int64, device=device)
+                    if (needs_z and not explicit) else None)
 
-        # A captured denoising step is kept across calls (the evaluator samples once per environment step,
-        # evaluator.py:272-277): the graph reads persistent buffers, so a later call with the same shapes and unchanged
-        # weights only copies its inputs in and replays.  One entry is kept (its activations are the memory cost).
+        # The captured loop is kept across calls (the evaluator samples once per environment step, evaluator.py:272-277): the
+        # graph reads persistent buffers, so a later call with the same shapes and unchanged weights only copies its inputs
+        # in and replays.  One entry is kept (its activations are the memory cost).
+        chunk = self._graph_chunk(n_steps)
         key = (shape, str(device), id(sched), n_steps, returns is not None, None if env_ts is None else tuple(env_ts.shape),
-               ops._PRECISION, ops._EPOCH, sum(p_._version for p_ in self.model.parameters()), self.condition_guidance_w)
+               ops._PRECISION, ops._EPOCH, sum(p_._version for p_ in self.model.parameters()), self.condition_guidance_w,
+               explicit, chunk)
         ent = _SAMPLE_CACHE.get(self)
         if not (use_graph and ent is not None and ent["key"] == key):
             ent = None
         if ent is not None:
             st, returns_s, env_ts_s, graph = ent["st"], ent["returns"], ent["env_ts"], ent["graph"]
-            st["x"].copy_(x0)
             st["cond_x"].copy_(cond["x"])
             st["mask"].copy_(cond["masks"])
-            st["state"].zero_()
             if returns_s is not None:
                 returns_s.copy_(returns)
             if env_ts_s is not None:
                 env_ts_s.copy_(env_ts)
         else:
             _SAMPLE_CACHE.pop(self, None)
-            st = {"x": x0.clone().contiguous(), "cond_x": cond["x"].to(device, torch.float32).contiguous().clone(),
+            st = {"x": torch.empty(shape, dtype=torch.float32, device=device),
+                  "cond_x": cond["x"].to(device, torch.float32).contiguous().clone(),
                   "mask": cond["masks"].to(device=device, dtype=torch.uint8).contiguous().clone(),
                   "coef": tb["coef"], "tsteps": tb["timesteps"],
                   "state": torch.zeros(1, dtype=torch.int32, device=device),
                   "ts": torch.zeros(batch_size, dtype=torch.int64, device=device),
-                  "z": torch.empty(shape, dtype=torch.float32, device=device) if needs_z else None}
+                  "rng": torch.zeros(2, dtype=torch.int64, device=device),
+                  "z_all": torch.zeros((n_steps,) + shape, dtype=torch.float32, device=device) if explicit else None}
             returns_s = None if returns is None else returns.clone()
             env_ts_s = None if env_ts is None else env_ts.to(device).contiguous().clone()
             graph = None
-        ops.inpaint_(st["x"], st["cond_x"], st["mask"])           # step 1 of the first iteration (diffusion.py:251)
+
+        def reset():
+            st["x"].copy_(x0)
+            st["state"].zero_()
+            ops.inpaint_(st["x"], st["cond_x"], st["mask"])       # step 1 of the first iteration (diffusion.py:251)
+
+        if explicit:
+            rows = min(n_steps, step_noise.shape[0])               # (the last step, t = 0, has sigma = 0: its row is never read)
+            st["z_all"][:rows].copy_(step_noise[:rows].to(device, torch.float32).reshape((rows,) + shape))
+        elif rng_host is not None:
+            st["rng"].copy_(rng_host)
+        reset()
         chain = [st["x"].clone()] if return_diffusion else None
-
-        def draw(i):
-            if not needs_z:
-                return
-            if step_noise is not None:
-                if i < step_noise.shape[0]:
-                    st["z"].copy_(step_noise[i])
-            else:
-                st["z"].normal_()
-
-        for i in range(n_steps):
-            draw(i)
-            if graph is not None:
-                graph.replay()
-            elif use_graph and i == 1 and n_steps > 2:
-                # iteration 0 ran eagerly (it filled the weight-pack cache and warmed the allocator); capture
-                # iteration 1 and replay it for the rest: the step index lives on the device, so one captured
-                # step serves every iteration.  Capture does not execute, hence the replay right after.
+        if use_graph and n_steps > 1:
+            if graph is None:
+                # one eager iteration first (it fills the weight-pack cache, tunes kernel variants and warms the allocator),
+                # then the loop is captured: `chunk` iterations per graph (all K by default), each reading the step index
+                # from the device.  Capture does not execute; the replays below do.
+                self._denoise_step(st, returns_s, env_ts_s, batch_size, t_len)
+                reset()
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with ops.graph_capture(graph):
-                    self._denoise_step(st, returns_s, env_ts_s, batch_size, t_len)
+                    for _ in range(chunk):
+                        self._denoise_step(st, returns_s, env_ts_s, batch_size, t_len)
+                _SAMPLE_CACHE[self] = {"key": key, "st": st, "returns": returns_s, "env_ts": env_ts_s, "graph": graph,
+                                       "chunk": chunk}
+            for _ in range(n_steps // chunk):
                 graph.replay()
-                _SAMPLE_CACHE[self] = {"key": key, "st": st, "returns": returns_s, "env_ts": env_ts_s, "graph": graph}
-            else:
+            self.last_sample_launches = n_steps // chunk          # host launches of the K-step loop (1 = whole-loop graph)
+            x = st["x"].clone()                                    # (the persistent buffer is reused by the next call)
+        else:
+            for i in range(n_steps):
                 self._denoise_step(st, returns_s, env_ts_s, batch_size, t_len)
-            if return_diffusion:
-                chain.append(st["x"].clone())
-        x = st["x"].clone() if graph is not None else st["x"]     # (the persistent buffer is reused by the next call)
+                if return_diffusion:
+                    chain.append(st["x"].clone())
+            self.last_sample_launches = None
+            x = st["x"]
         # the posterior kernel already enforced the final conditioning (diffusion.py:268); then the encoder (:269)
         x = self._encode_(x)
         if return_diffusion:

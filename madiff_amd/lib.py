@@ -50,6 +50,7 @@ _SIGS = {
     "madiff_attn_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_attn_bwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_attn_bwd_rb": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "madiff_attn_mfma_covers": [_i, _i, _i, _i, _i, _i],
     "madiff_pack_input": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_loss_ws_doubles": [],
     "madiff_loss_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -63,6 +64,7 @@ _SIGS = {
     "madiff_inv_pairs": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "madiff_unpack_output": [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "madiff_posterior_step": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp],
+    "madiff_posterior_step_rng": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp],
     "madiff_inpaint": [_vp, _vp, _vp, _l, _vp],
     "madiff_encode_first_k": [_vp, _i, _i, _i, _i, _i, _vp],
     "madiff_sampler_fill_time": [_vp, _vp, _vp, _i, _vp],

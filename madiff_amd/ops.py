@@ -1362,8 +1362,12 @@ class ConvBlock(torch.autograd.Function):
     apply(x, x2, rowbias, res, spec, t_in, G, w, b, gamma, beta)"""
 
     @staticmethod
-    def forward(ctx, x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w, b, gamma, beta):
-        fused = _conv_block_fused(x, x2, rowbias, res, spec, t_in, G, w, b, gamma, beta, any(ctx.needs_input_grad))
+    def forward(ctx, x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w, b, gamma, beta, grad_on=True):
+        # grad_on = torch.is_grad_enabled() at the call (inside forward() autograd is always off, and needs_input_grad
+        # follows requires_grad whatever the grad mode): under no_grad -- the sampler -- the fused kernel must not write the
+        # pre-norm output and the statistics, which only backward reads
+        fused = _conv_block_fused(x, x2, rowbias, res, spec, t_in, G, w, b, gamma, beta,
+                                  bool(grad_on) and any(ctx.needs_input_grad))
         if fused is not None:
             out, y, stats, g, geom = fused
         else:
@@ -1379,7 +1383,7 @@ class ConvBlock(torch.autograd.Function):
         needs = ctx.needs_input_grad
         dy, dgamma, dbeta, dbias, drb, dres = _gn_backward(y, gamma, beta, stats, ctx.geom, dout, conv_bias=b)
         dx, dx2, _, gw, _ = _conv_backward(ctx.g, x, x2, [w], [b], dy, needs[0], needs[1], [needs[7]], "none", False)
-        return (dx, dx2, drb, dres if ctx.geom[5] == 2 else None, None, None, None, gw[0], dbias, dgamma, dbeta)
+        return (dx, dx2, drb, dres if ctx.geom[5] == 2 else None, None, None, None, gw[0], dbias, dgamma, dbeta, None)
 
 
 class ResBlock(torch.autograd.Function):
@@ -1393,8 +1397,9 @@ class ResBlock(torch.autograd.Function):
     (rw / rb None: identity residual; chain_out / chain_in: ChainTag | None, see there)"""
 
     @staticmethod
-    def forward(ctx, x, x2, temb, t_in: int, G: int, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb, chain_out=None, chain_in=None):
-        need = any(ctx.needs_input_grad)
+    def forward(ctx, x, x2, temb, t_in: int, G: int, w0, b0, g0, be0, w1, b1, g1, be1, rw, rb, chain_out=None, chain_in=None,
+                grad_on=True):
+        need = bool(grad_on) and any(ctx.needs_input_grad)      # (grad_on: see ConvBlock.forward)
 
         def block(xa, xb, rowbias, res, w, b, gamma, beta):
             fused = _conv_block_fused(xa, xb, rowbias, res, CONV5, t_in, G, w, b, gamma, beta, need)
@@ -1471,20 +1476,20 @@ class ResBlock(torch.autograd.Function):
             dx, dx2, _, gw0, _ = _conv_backward(cg0, x, x2, [w0], [b0], dy0, needs[0], needs[1], [needs[5]], "none", False,
                                                 addends=(dxr, dx2r))
         return (dx, dx2, drb if needs[2] else None, None, None, gw0[0], dbias0, dgamma0, dbeta0, gw1[0], dbias1, dgamma1,
-                dbeta1, gwr[0], gbr[0], None, None)
+                dbeta1, gwr[0], gbr[0], None, None, None)
 
 
 def res_block(x, x2, temb, t_in: int, G: int, blk0, blk1, rw=None, rb=None, chain_out=None, chain_in=None):
     """blk0 / blk1 = (weight, bias, gamma, beta) of the two Conv1dBlocks; chain_out / chain_in: ChainTag | None."""
     if x2 is not None and x.shape[1] % 128 != 0:   # the split-source kernels need 128-aligned halves
         x, x2 = torch.cat((x, x2), dim=1), None
-    return ResBlock.apply(x, x2, temb, t_in, G, *blk0, *blk1, rw, rb, chain_out, chain_in)
+    return ResBlock.apply(x, x2, temb, t_in, G, *blk0, *blk1, rw, rb, chain_out, chain_in, torch.is_grad_enabled())
 
 
 def conv_block(x, w, b, gamma, beta, spec: ConvSpec, t_in: int, G: int, x2=None, rowbias=None, res=None):
     if x2 is not None and x.shape[1] % 128 != 0:
         x, x2 = torch.cat((x, x2), dim=1), None
-    return ConvBlock.apply(x, x2, rowbias, res, spec, t_in, G, w, b, gamma, beta)
+    return ConvBlock.apply(x, x2, rowbias, res, spec, t_in, G, w, b, gamma, beta, torch.is_grad_enabled())
 
 
 class GNMish(torch.autograd.Function):
@@ -1504,6 +1509,12 @@ class GNMish(torch.autograd.Function):
         return dy, dgamma, dbeta, drb, (dres if ctx.geom[5] == 2 else None), None, None, None, None
 
 
+def _attn_label(kind: str, A, T, H, Cq, C) -> str:
+    """Name of the kernel madiff_attn_{fwd,bwd} dispatches to (bench.py's per-family records follow rocprofv3's names)."""
+    mfma = _PRECISION == "bf16" and lib._lib.madiff_attn_mfma_covers(lib.BF16, A, T, H, Cq, C) == 1
+    return f"attn_{kind}_mfma_kernel" if mfma else f"attn_{kind}_v2_kernel"
+
+
 class AttnCore(torch.autograd.Function):
     """softmax over agents of q.k, times v, then x + gamma*out; qkv is the fused projection [M, 2Cq + C]."""
 
@@ -1514,7 +1525,7 @@ class AttnCore(torch.autograd.Function):
         out = torch.empty_like(x)
         if out.shape[1] > C:
             out[:, C:].zero_()
-        _timed("attn_fwd_v2_kernel", 0.0, lambda: lib.call(             # bytes: read qkv and x, write out
+        _timed(_attn_label("fwd", A, T, H, Cq, C), 0.0, lambda: lib.call(   # bytes: read qkv and x, write out
             "madiff_attn_fwd", _dt(), qkv.data_ptr(), qkv.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
             out.stride(0), _p(gamma), B, A, T, H, Cq, C, int(residual), _stream()),
             nbytes=float(B * A * T * (2 * Cq + 3 * C) * x.element_size()))
@@ -1532,7 +1543,7 @@ class AttnCore(torch.autograd.Function):
             dqkv[:, 2 * Cq + C:].zero_()
         view = _sink_view(gamma) if residual else None
         dgamma = view if view is not None else (torch.zeros(1, dtype=torch.float32, device=qkv.device) if residual else None)
-        _timed("attn_bwd_v2_kernel", 0.0, lambda: lib.call(             # bytes: read qkv and dout, write dqkv
+        _timed(_attn_label("bwd", A, T, H, Cq, C), 0.0, lambda: lib.call(   # bytes: read qkv and dout, write dqkv
             "madiff_attn_bwd", _dt(), qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0),
             dqkv.data_ptr(), dqkv.stride(0), _p(gamma), _p(dgamma), B, A, T, H, Cq, C, int(residual), _stream()),
             nbytes=float(B * A * T * (2 * (2 * Cq + C) + C) * qkv.element_size()))
@@ -1559,7 +1570,7 @@ class AttnBlock(torch.autograd.Function):
         out = torch.empty_like(x)
         if out.shape[1] > C:
             out[:, C:].zero_()
-        _timed("attn_fwd_v2_kernel", 0.0, lambda: lib.call(
+        _timed(_attn_label("fwd", A, T, H, Cq, C), 0.0, lambda: lib.call(
             "madiff_attn_fwd", _dt(), qkv.data_ptr(), qkv.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
             out.stride(0), _p(gamma), B, A, T, H, Cq, C, int(residual), _stream()),
             nbytes=float(B * A * T * (2 * Cq + 3 * C) * x.element_size()))
@@ -1588,7 +1599,7 @@ class AttnBlock(torch.autograd.Function):
             drb = slot_view(ctx.rb_slot, B * A, ncol)
             if drb is None:
                 drb = torch.empty(B * A, ncol, dtype=torch.float32, device=qkv.device)
-        _timed("attn_bwd_v2_kernel", 0.0, lambda: lib.call(
+        _timed(_attn_label("bwd", A, T, H, Cq, C), 0.0, lambda: lib.call(
             "madiff_attn_bwd_rb", _dt(), qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0), dqkv.data_ptr(),
             dqkv.stride(0), _p(gamma), _p(dgamma), _p(drb), 0 if drb is None else drb.stride(0), B, A, T, H, Cq, C,
             int(residual), _stream()), nbytes=float(B * A * T * (2 * ncol + C) * qkv.element_size()))
@@ -1847,6 +1858,14 @@ class FusedLoss(torch.autograd.Function):
 def posterior_step(x, eps_c, eps_u, w, z, cond, mask_u8, coef, out, step_ptr=None, step_val=0):
     lib.call("madiff_posterior_step", x.data_ptr(), eps_c.data_ptr(), _p(eps_u), float(w), _p(z), _p(cond), _p(mask_u8),
              coef.data_ptr(), _p(step_ptr), int(step_val), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+def posterior_step_rng(x, eps_c, eps_u, w, z_all, rng, cond, mask_u8, coef, out, step_ptr=None, step_val=0):
+    """posterior_step with the noise taken on the device: row `step` of z_all [n_steps, numel] (explicit draws) or, when
+    z_all is None, Philox4x32-10 normals keyed by rng (int64[2] on the device = {seed, stream id})."""
+    lib.call("madiff_posterior_step_rng", x.data_ptr(), eps_c.data_ptr(), _p(eps_u), float(w), _p(z_all), _p(rng), _p(cond),
+             _p(mask_u8), coef.data_ptr(), _p(step_ptr), int(step_val), out.data_ptr(), x.numel(), _stream())
     return out
 
 

@@ -238,8 +238,11 @@ def test_gn_mish(prec, mode, shape):
         assert rel_err(a.cpu(), b.cpu()) < TOL[prec] * (3 if prec == "bf16" else 2)
 
 
-@pytest.mark.parametrize("geom", [(3, 3, 6, 64), (2, 8, 6, 128), (2, 4, 12, 512)])
+@pytest.mark.parametrize("geom", [(3, 3, 6, 64), (2, 8, 6, 128), (2, 4, 12, 512), (5, 3, 6, 1024), (3, 8, 6, 1024),
+                                  (2, 6, 7, 512), (9, 4, 14, 512)])
 def test_attention_core(prec, geom):
+    """(.., 512) and (.., 1024): head slices of 32 / 128 and 64 / 256 features -> the MFMA form in the bf16 build (packed
+    rows; B not a multiple of the 4 or 2 batch elements per tile, A = 3 and 6 padded to 4 and 8); narrower ones: v2 / v1."""
     from madiff_amd import modules as M, ops
     dev = _dev()
     B, A, T, C = geom
@@ -267,6 +270,21 @@ def test_attention_core(prec, geom):
     assert rel_err(out.detach().float().cpu(), ref.detach().cpu()) < TOL[prec]
     for a, b in zip(torch.autograd.grad(out, [q2, x2, g2], gy.to(ops.act_dtype())), gref):
         assert rel_err(a.float().cpu(), b.cpu()) < TOL[prec] * (3 if prec == "bf16" else 2)
+    if prec == "bf16":
+        assert ops.lib._lib.madiff_attn_mfma_covers(ops.lib.BF16, A, T, H, Cq, C) == int(C >= 512)
+    # the row-bias gradient of the fused projection through the C ABI: drb[(b,a), col] = sum_t dqkv[(b,a,t), col]
+    qk = q2.detach().to(ops.act_dtype()).contiguous()
+    g = gy.to(ops.act_dtype()).contiguous()
+    dqkv = torch.empty_like(qk)
+    dgam = torch.zeros(1, device=dev)
+    drb = torch.full((B * A, W), float("nan"), device=dev)
+    ops.lib.call("madiff_attn_bwd_rb", ops._dt(), qk.data_ptr(), qk.stride(0), g.data_ptr(), g.stride(0), dqkv.data_ptr(),
+                 dqkv.stride(0), g2.data_ptr(), dgam.data_ptr(), drb.data_ptr(), drb.stride(0), B, A, T, H, Cq, C, 1,
+                 ops._stream())
+    assert rel_err(dqkv.float().cpu(), gref[0].cpu()) < TOL[prec] * (3 if prec == "bf16" else 2)
+    assert abs(float(dgam) - float(gref[2])) < TOL[prec] * 3 * max(abs(float(gref[2])), 1.0)
+    want = gref[0].reshape(B * A, T, W).sum(dim=1)
+    assert rel_err(drb.cpu(), want.cpu()) < TOL[prec] * (3 if prec == "bf16" else 2)
 
 
 def test_pack_unpack_noise_inpaint(prec):
@@ -330,6 +348,40 @@ def test_posterior_and_mse():
     assert abs(a0.item() - l.mean().item()) < 2e-6 * abs(l.mean().item())
     g2, = torch.autograd.grad(loss, p2)
     assert rel_err(g2.cpu(), gref.cpu()) < 1e-5
+
+
+def test_posterior_step_device_noise_matches_philox_oracle():
+    """madiff_posterior_step_rng: (a) with an explicit per-step table it equals madiff_posterior_step on that row;
+    (b) with rng = {seed, stream} its noise is Philox4x32-10 + Box-Muller word for word (oracle.philox_normal, pinned by the
+    published known-answer vectors in tests/test_scheduler.py): coefficient row {0, 1, 0, 0, 0, 1} makes out = z."""
+    from madiff_amd import ops
+    from madiff_amd.schedulers import DDPMScheduler
+    from oracle import madiff_oracle as O
+    dev = _dev()
+    B, T, A, Fd = 3, 6, 3, 17                                   # 918 elements: not a multiple of 4 (ragged last quad)
+    x, ec, eu, cond = [_rand(B, T, A, Fd, seed=i, scale=1.5).to(dev) for i in range(4)]
+    mask = (torch.rand(B, T, A, Fd, generator=torch.Generator().manual_seed(9)) < 0.2).to(dev).to(torch.uint8)
+    coef = DDPMScheduler(num_train_timesteps=200).coef_table().to(dev)
+    z_all = torch.stack([_rand(B, T, A, Fd, seed=20 + i) for i in range(4)]).to(dev)
+    state = torch.tensor([2], dtype=torch.int32, device=dev)
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    ops.posterior_step(x, ec, eu, 1.2, z_all[2].contiguous(), cond, mask, coef, a, step_val=2)
+    ops.posterior_step_rng(x, ec, eu, 1.2, z_all, None, cond, mask, coef, b, step_ptr=state)
+    assert torch.equal(a, b)
+    unit = torch.tensor([[0, 1, 0, 0, 0, 1]] * 8, dtype=torch.float32, device=dev)
+    zero = torch.zeros_like(x)
+    seed, stream = 0x0123456789ABCDEF, 0x1_0000_0007
+    rng = torch.tensor([seed, stream], dtype=torch.int64, device=dev)
+    for step in (0, 5):
+        out = torch.empty_like(x)
+        ops.posterior_step_rng(zero, zero, None, 0.0, None, rng, None, None, unit, out, step_val=step)
+        ref = O.philox_normal(seed, stream, step, x.numel()).reshape(x.shape)
+        assert np.abs(out.cpu().numpy().astype(np.float64) - ref).max() < 2e-5        # fp32 log / sincos against float64
+    big = torch.zeros(1 << 20, device=dev)
+    out = torch.empty_like(big)
+    ops.posterior_step_rng(big, big, None, 0.0, None, rng, None, None, unit, out, step_val=1)
+    assert abs(float(out.mean())) < 4e-3 and abs(float(out.std()) - 1) < 4e-3
+    assert np.abs(out[:4096].cpu().numpy() - O.philox_normal(seed, stream, 1, 4096)).max() < 2e-5
 
 
 def test_sinusoid_and_activations(prec):

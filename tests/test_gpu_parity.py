@@ -470,6 +470,40 @@ def test_sampling_vs_reference_golden(golden, tag, name, width, K, use_graph):
         ops.set_precision("bf16")
 
 
+def test_whole_loop_graph_is_one_launch_and_matches_eager(prec):
+    """The K-step loop (diffusion.py:249-263) as ONE hipGraph launch with the scheduler's noise drawn on the device: same
+    seed -> the eager loop and the captured loop give the same trajectories bit for bit (the same kernels on the same
+    Philox draws), a second call replays the kept graph with fresh draws, and the chunked form (MADIFF_SAMPLE_GRAPH_STEPS)
+    agrees too."""
+    import os
+    dev = torch.device("cuda:0")
+    A, Tt, Fd, hh = SHAPES["spread"]
+    K = 20
+    dif, act = build("spread", 16, K)
+    batch = O.synthetic_batch(3, Tt, A, Fd, act, hh, False, 0, seed=23)
+    cond = {k: v.to(dev) for k, v in batch["cond"].items()}
+    ret = batch["returns"].to(dev)
+    x_init = 0.5 * T(O.closed_form_normal("wl.0", (3, Tt, A, Fd)), dev)
+    torch.manual_seed(77)
+    eager = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, use_graph=False)
+    assert dif.last_sample_launches is None
+    torch.manual_seed(77)
+    g1 = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, use_graph=True)
+    assert dif.last_sample_launches == 1
+    assert torch.equal(g1, eager)
+    g2 = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, use_graph=True)      # replay, new seed
+    assert not torch.equal(g2, g1) and bool(torch.isfinite(g2).all())
+    m = batch["cond"]["masks"].numpy()
+    assert np.array_equal(g2.cpu().numpy()[m], batch["cond"]["x"].numpy()[m])
+    os.environ["MADIFF_SAMPLE_GRAPH_STEPS"] = "6"              # largest divisor of 20 below 6: 5 steps per graph, 4 replays
+    try:
+        torch.manual_seed(77)
+        g3 = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, use_graph=True)
+        assert dif.last_sample_launches == 4 and torch.equal(g3, eager)
+    finally:
+        del os.environ["MADIFF_SAMPLE_GRAPH_STEPS"]
+
+
 def test_ddim_vs_reference_golden(golden):
     from madiff_amd import ops
     ops.set_precision("fp32")

@@ -59,3 +59,21 @@ def test_ddim_timesteps():
     d = DDIMSchedule(200, 15)
     assert d.ratio == 13
     assert d.timesteps.tolist() == [13 * i for i in range(14, -1, -1)]
+
+
+def test_philox4x32_10_known_answers():
+    """The oracle's restatement of the counter-based generator behind the sampler's device-side noise, against the
+    known-answer vectors published with the algorithm (Random123 kat_vectors, philox4x32 10 rounds)."""
+    from oracle.madiff_oracle import philox4x32_10, philox_normal
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(np.array([ctr], dtype=np.uint32), np.array(key, dtype=np.uint32))[0]
+        assert tuple(int(v) for v in got) == want
+    z = philox_normal(seed=0x1234567890ABCDEF, stream=5, step=17, numel=(1 << 18) + 3)
+    assert z.shape == ((1 << 18) + 3,)
+    assert abs(z.mean()) < 6e-3 and abs(z.std() - 1) < 6e-3 and abs((z ** 4).mean() - 3) < 0.08
+    z2 = philox_normal(seed=0x1234567890ABCDEF, stream=5, step=18, numel=1 << 18)
+    assert abs(np.corrcoef(z[: 1 << 18], z2)[0, 1]) < 8e-3         # another step: another stream of draws

@@ -115,7 +115,7 @@ def test_two_rank_sharded_sampling_matches_unsharded():
     ref = s.conditional_sample(cond, returns, x_init=x_init, step_noise=step_noise)
     assert x0.shape == ref.shape == (B, T, A, FD)
     # same arithmetic per episode; CPU GEMM blocking may differ with the batch size, hence not bitwise
-    assert (x0 - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert (x0 - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
     assert torch.equal(x0[:, :1], cond["x"][:, :1])     # inpainting survives the gather
 
 
