@@ -534,7 +534,8 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_attn_bwd_v2(int dtyp
 //
 // Against v2 (one workgroup per (b, h), q/k staged in LDS as fp32, scores by wave_sum loops) this form has every global
 // load of a phase in flight at once and 4 (A <= 4) or 2 (A <= 8) batch elements per workgroup.  The row-bias gradient
-// (sum over t of dqkv, temporal.py:100-111's time conditioning) is accumulated with LDS atomics while dqkv is produced.
+// (sum over t of dqkv, temporal.py:100-111's time conditioning) is formed from sums over t of the INPUT rows, mixed with
+// P / dS at the end (LDS float atomics on the outputs were tried first: 46 us of a 64 us launch).
 // Needs d_qk % 32 == 0 and d_v % 32 == 0 (dim 128: 64 / 256 and 32 / 128); other shapes and the fp32 build use v2.
 // ================================================================================================
 template <int AP>
@@ -550,27 +551,41 @@ __device__ __forceinline__ void att3_softmax_row(const float* s, int A, float* p
   for (int j = 0; j < AP; j++) p[j] = j < A ? p[j] * inv : 0.f;
 }
 
-// acc += X[rho1] . Y[rho2] over the wave's share of the K-steps: K-step s = (t, 32-feature block j) of a head slice that is
-// `dh` features wide; xrow / yrow = this lane's packed row at feature offset fq * 8 of the slice (t = 0)
+// acc += X[rho1] . Y[rho2] over the wave's share of a head slice that is `dh` features wide (dh % 32 == 0).  The order of the
+// contraction index is free as long as both operands use the same one, so a 64-byte K-step is NOT "lane group fq takes
+// bytes [16 fq, 16 fq + 16)": the slice of one time step is cut into 128-byte units (64 features = two MFMAs; a last half
+// unit when dh % 64 == 32), lane group fq loads the 32 contiguous bytes [32 fq, 32 fq + 32) of a unit and feeds its two
+// halves to the two MFMAs -- a wave then reads whole 128-byte lines of 16 rows per unit.  Units are dealt out to the waves
+// in contiguous runs.  xrow / yrow = this lane's packed row (t = 0) at the start of the head slice.
 template <int NW>
 __device__ __forceinline__ f32x4 att3_rowdots(const bf16_t* __restrict__ xrow, int ldx, const bf16_t* __restrict__ yrow, int ldy,
-                                              int Tn, int dh, int wave) {
-  const int spt = dh >> 5, nks = Tn * spt;
+                                              int Tn, int dh, int wave, int fq) {
+  const int upt = (dh + 63) >> 6, nu = Tn * upt;            // units per time step, units in all
+  const bool half_tail = (dh & 63) != 0;                    // the last unit of a time step holds 32 features only
+  const int per = (nu + NW - 1) / NW, u_lo = wave * per, u_hi = min(nu, u_lo + per);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  // four K-steps per round: their eight 16-byte loads are issued together, then the MFMAs (a round's tail steps beyond the
-  // slice re-read the last step and are skipped by a wave-uniform branch)
-  for (int s0 = wave; s0 < nks; s0 += 4 * NW) {
-    bf16x8 a[4], b[4];
+  for (int u0 = u_lo; u0 < u_hi; u0 += 2) {                 // two units per round: eight 16-byte loads in flight per lane
+    bf16x8 a[2][2], b[2][2];
+    bool two[2];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int s = min(s0 + u * NW, nks - 1);
-      const int t = s / spt, j = s - t * spt;
-      a[u] = *(const bf16x8*)(xrow + (size_t)t * ldx + j * 32);
-      b[u] = *(const bf16x8*)(yrow + (size_t)t * ldy + j * 32);
+    for (int k = 0; k < 2; k++) {
+      const int u = min(u0 + k, u_hi - 1);
+      const int t = u / upt, j = u - t * upt;
+      two[k] = !(half_tail && j == upt - 1);
+      // full unit: bytes [32 fq, 32 fq + 32) of the 128-byte unit; half unit (64 bytes): [16 fq, 16 fq + 16) only
+      const int off = j * 64 + (two[k] ? fq * 16 : fq * 8);
+      const bf16_t* px = xrow + (size_t)t * ldx + off;
+      const bf16_t* py = yrow + (size_t)t * ldy + off;
+      a[k][0] = *(const bf16x8*)px;
+      b[k][0] = *(const bf16x8*)py;
+      if (two[k]) { a[k][1] = *(const bf16x8*)(px + 8); b[k][1] = *(const bf16x8*)(py + 8); }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (s0 + u * NW < nks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
+    for (int k = 0; k < 2; k++) {
+      if (u0 + k >= u_hi) continue;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k][0], b[k][0], acc, 0, 0, 0);
+      if (two[k]) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k][1], b[k][1], acc, 0, 0, 0);
+    }
   }
   return acc;
 }
@@ -602,8 +617,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(const bf16_t* __
   {
     const int pb = fr / AP, pa = fr - pb * AP;
     const int rb = (pa < A && b0 + pb < B) ? (b0 + pb) * A + pa : b0 * A;
-    const bf16_t* qrow = qkv + (size_t)rb * Tn * ldq + h * dqk + fq * 8;
-    const f32x4 acc = att3_rowdots<NW>(qrow, ldq, qrow + Cq, ldq, Tn, dqk, wave);
+    const bf16_t* qrow = qkv + (size_t)rb * Tn * ldq + h * dqk;
+    const f32x4 acc = att3_rowdots<NW>(qrow, ldq, qrow + Cq, ldq, Tn, dqk, wave, fq);
 #pragma unroll
     for (int r = 0; r < 4; r++) Sp[wave][(fq * 4 + r) * 16 + fr] = acc[r];
   }
@@ -674,17 +689,43 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(const bf16_t* __
   const int dqk = Cq / H, dv = C / H, W = 2 * dqk + dv;
   const int bg = blockIdx.x / H, h = blockIdx.x - bg * H, b0 = bg * G;
   const float gamma = residual ? gamma_p[0] : 1.f;
-  if (drb)
-    for (int i = tid; i < 16 * W; i += NT) Rs[i] = 0.f;
+  // Row-bias gradient (drb[(b,a), col] = sum_t dqkv[(b,a,t), col]) without touching dqkv again and without atomics: the
+  // sums over t commute with the K = A mixes, sum_t dq[a1] = sum_a2 dS[a1][a2] (sum_t k[a2]) and likewise for dk and dv,
+  // so the workgroup first sums its rows of q, k and dO over t into Rs = [q sums | k sums | dO sums] per packed row (loads
+  // that overlap the MFMA phase below; the second read of these rows comes from cache) and mixes the sums at the end.
+  if (drb) {
+    const int w8 = W >> 3;
+    for (int i = tid; i < 16 * w8; i += NT) {
+      const int rho = i / w8, c = (i - rho * w8) * 8;
+      const int pb = rho / AP, pa = rho - pb * AP;
+      float sum[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) sum[e] = 0.f;
+      if (pa < A && b0 + pb < B) {
+        const size_t row0 = (size_t)((b0 + pb) * A + pa) * Tn;
+        const bf16_t* src;
+        int ld;
+        if (c < 2 * dqk) { src = qkv + row0 * ldq + (c < dqk ? h * dqk + c : Cq + h * dqk + (c - dqk)); ld = ldq; }
+        else { src = dout + row0 * ldd + h * dv + (c - 2 * dqk); ld = ldd; }
+        for (int t = 0; t < Tn; t++) {
+          const bf16x8 v = *(const bf16x8*)(src + (size_t)t * ld);
+#pragma unroll
+          for (int e = 0; e < 8; e++) sum[e] += (float)v[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) Rs[rho * W + c + e] = sum[e];
+    }
+  }
   // ---- S = Q K^T and raw dP = dO V^T on MFMA (packed rows, operands straight from global memory)
   {
     const int pb = fr / AP, pa = fr - pb * AP;
     const int rb = (pa < A && b0 + pb < B) ? (b0 + pb) * A + pa : b0 * A;
-    const bf16_t* qrow = qkv + (size_t)rb * Tn * ldq + h * dqk + fq * 8;
-    const bf16_t* vrow = qkv + (size_t)rb * Tn * ldq + 2 * Cq + h * dv + fq * 8;
-    const bf16_t* grow = dout + (size_t)rb * Tn * ldd + h * dv + fq * 8;
-    const f32x4 accd = att3_rowdots<NW>(grow, ldd, vrow, ldq, Tn, dv, wave);
-    const f32x4 accs = att3_rowdots<NW>(qrow, ldq, qrow + Cq, ldq, Tn, dqk, wave);
+    const bf16_t* qrow = qkv + (size_t)rb * Tn * ldq + h * dqk;
+    const bf16_t* vrow = qkv + (size_t)rb * Tn * ldq + 2 * Cq + h * dv;
+    const bf16_t* grow = dout + (size_t)rb * Tn * ldd + h * dv;
+    const f32x4 accd = att3_rowdots<NW>(grow, ldd, vrow, ldq, Tn, dv, wave, fq);
+    const f32x4 accs = att3_rowdots<NW>(qrow, ldq, qrow + Cq, ldq, Tn, dqk, wave, fq);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       Sp[wave][(fq * 4 + r) * 16 + fr] = accs[r];
@@ -725,7 +766,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(const bf16_t* __
   const int vprv = dv >> 3, nvv = G * Tn * vprv, vprq = dqk >> 3, nvq = G * Tn * vprq;
   for (int i = tid; i < nvv + nvq; i += NT) {
     if (i < nvv) {
-      const int cv = i % vprv, r = i / vprv, t = r % Tn, pb = r / Tn;
+      // (cv fastest, then the batch element, then t: the lanes of a wave then add into different Rs entries)
+      const int cv = i % vprv, r = i / vprv, pb = r % G, t = r / G;
       const int b = b0 + pb;
       if (b >= B) continue;
       const int c = h * dv + cv * 8;
@@ -750,15 +792,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int e = 0; e < 8; e++) { o[e] *= gamma; ov[e] = (bf16_t)o[e]; }
         *(bf16x8*)(dqkv + ((size_t)(b * A + a2) * Tn + t) * ldg + 2 * Cq + c) = ov;
-        if (drb) {
-          float* rs = Rs + (pb * AP + a2) * W + 2 * dqk + cv * 8;
-#pragma unroll
-          for (int e = 0; e < 8; e++) atomicAdd(rs + e, o[e]);
-        }
       }
     } else {
       const int j = i - nvv;
-      const int cv = j % vprq, r = j / vprq, t = r % Tn, pb = r / Tn;
+      const int cv = j % vprq, r = j / vprq, pb = r % G, t = r / G;
       const int b = b0 + pb;
       if (b >= B) continue;
       const int c = h * dqk + cv * 8;
@@ -786,23 +823,34 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(const bf16_t* __
 #pragma unroll
           for (int e = 0; e < 8; e++) vv[e] = (bf16_t)ov[e];
           *(bf16x8*)(dqkv + ((size_t)(b * A + a) * Tn + t) * ldg + c + (part == 0 ? 0 : Cq)) = vv;
-          if (drb) {
-            float* rs = Rs + (pb * AP + a) * W + (part == 0 ? 0 : dqk) + cv * 8;
-#pragma unroll
-            for (int e = 0; e < 8; e++) atomicAdd(rs + e, ov[e]);
-          }
         }
       }
     }
   }
-  if (drb) {
-    __syncthreads();
+  if (drb) {      // (Rs was complete before the first barrier, Ps / Ds before the second)
     for (int i = tid; i < 16 * W; i += NT) {
       const int rho = i / W, c = i - rho * W;
       const int pb = rho / AP, a = rho - pb * AP;
       if (a >= A || b0 + pb >= B) continue;
-      const int col = c < dqk ? h * dqk + c : (c < 2 * dqk ? Cq + h * dqk + (c - dqk) : 2 * Cq + h * dv + (c - 2 * dqk));
-      drb[(size_t)((b0 + pb) * A + a) * ldrb + col] = Rs[i];
+      float v = 0.f;
+      int col;
+      if (c < dqk) {                      // sum_t dq[a] = sum_o dS[a][o] ksum[o]
+        col = h * dqk + c;
+#pragma unroll
+        for (int o = 0; o < AP; o++) if (o < A) v += Ds[rho * AP + o] * Rs[(pb * AP + o) * W + dqk + c];
+      } else if (c < 2 * dqk) {           // sum_t dk[a] = sum_o dS[o][a] qsum[o]
+        const int cc = c - dqk;
+        col = Cq + h * dqk + cc;
+#pragma unroll
+        for (int o = 0; o < AP; o++) if (o < A) v += Ds[(pb * AP + o) * AP + a] * Rs[(pb * AP + o) * W + cc];
+      } else {                            // sum_t dv[a] = gamma sum_o P[o][a] gsum[o]
+        const int cc = c - 2 * dqk;
+        col = 2 * Cq + h * dv + cc;
+#pragma unroll
+        for (int o = 0; o < AP; o++) if (o < A) v += Ps[(pb * AP + o) * AP + a] * Rs[(pb * AP + o) * W + c];
+        v *= gamma;
+      }
+      drb[(size_t)((b0 + pb) * A + a) * ldrb + col] = v;
     }
   }
 }

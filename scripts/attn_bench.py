@@ -16,7 +16,9 @@ def timeit(fn, n=30):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-B, A, H = 256, 4, 4
+A = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+B, H = 256, 4
+print(f"A={A} MADIFF_ATTN_MFMA={os.environ.get('MADIFF_ATTN_MFMA', '1')}", flush=True)
 for T, C in ((6, 1024), (12, 512), (24, 128)):
     Cq = C // 4
     M = B * A * T
