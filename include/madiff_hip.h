@@ -290,6 +290,19 @@ int madiff_loss_bwd_seg(const float* eps, const float* noise, const float* w, co
 int madiff_inv_pairs(int dtype, const float* x, void* out, int ld, int B, int T, int A, int act, int F, int joint,
                      madiff_stream_t stream);
 
+/* The embedding head of a denoiser forward in ONE launch (bf16 build, no autograd): SinusoidalPosEmb -> time_mlp
+ * (helpers.py:17-29, temporal.py:231-236), returns_mlp and the conditioning-dropout mask / force_dropout zeroing
+ * (temporal.py:244-252, ma_temporal.py:341-354), concatenated as [time | returns] per row (b, a).  Replaces ~25 dependent
+ * launches (sinusoid, five GEMMs, four Mish, mask, cat, casts) at the head of every one of the K denoising steps.
+ * W1 / W3 / M2 / M4: bf16 [O, ld] weight matrices in the GEMM layout; b* / c* / M0 (Linear(1, dim)): fp32 parameters.
+ * ret = NULL: no returns branch.  mask: fp32 [B*A] or NULL; force_zero: the unconditional pass.  act = 1 stores
+ * mish(value) (the only consumer is Linear(Mish(t_emb)), temporal.py:166-170).  out2 (may be NULL): the classifier-free
+ * guidance twin of every row (same time half, returns half zero, diffusion.py:195-202).  dim % 32 == 0, dim <= 128; returns
+ * 1 when the shape is not covered (caller: the separate launches). */
+int madiff_embed_mlp_fwd(const long* ts, const float* freq, const void* W1, int ld1, const float* b1, const void* W3, int ld3,
+                         const float* b3, const float* ret, const float* M0, const float* c0, const void* M2, int ldm2,
+                         const float* c2, const void* M4, int ldm4, const float* c4, const float* mask, int force_zero,
+                         void* out, int ldo, void* out2, int B, int A, int dim, int act, madiff_stream_t stream);
 /* SinusoidalPosEmb (helpers.py:17-29) for timesteps ts[B], repeated over A agents: out [B*A, ld], cols >= 2*half zeroed. */
 int madiff_sinusoid(int dtype, const long* ts, const float* freq, void* out, int ld, int B, int A, int half,
                     madiff_stream_t stream);

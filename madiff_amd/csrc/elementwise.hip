@@ -500,6 +500,124 @@ extern "C" int madiff_mse_bwd(const float* pred, const float* targ, const float*
   return 0;
 }
 
+// ---------------------------------------------------------------- the embedding head in ONE launch (bf16 build, inference)
+// temporal.py:231-252 + ma_temporal.py:341-354: t -> SinusoidalPosEmb -> Linear(dim, 4 dim) -> Mish -> Linear(4 dim, dim)   (y = 0)
+//                                               r -> Linear(1, dim) -> Mish -> Linear(dim, 4 dim) -> Mish -> Linear(4 dim, dim),
+//                                               times the dropout mask / zero under force_dropout                      (y = 1)
+// and the concatenation [time | returns] -- ~25 dependent launches of a few microseconds each at the head of every denoiser
+// forward (sinusoid, five GEMMs, four Mish, mask, cat, casts), which is what the small-batch sampler (the evaluator's 10
+// environments: one graph node costs ~10 us whatever it computes) and every one of the K denoising steps pay first.
+// One workgroup = 16 rows (b, a) of one of the two MLPs (blockIdx.y); both wide layers run on v_mfma_f32_16x16x32_bf16 with
+// the A operand in LDS (the 16 rows) and the B operand -- 8 consecutive k of weight row n, the GEMM layout [O, pad32(I)] the
+// other kernels use -- loaded straight from global memory into the fragment registers.  act = 1 stores mish(value): the
+// only consumer is Linear(Mish(t_emb)) (temporal.py:166-170, 60-72).  out2 (may be null) receives the classifier-free
+// guidance twin of every row: same time half, returns half forced to zero (diffusion.py:195-202).
+__global__ __launch_bounds__(256) void embed_mlp_fwd_kernel(
+    const long* __restrict__ ts, const float* __restrict__ freq, const bf16_t* __restrict__ W1, int ld1,
+    const float* __restrict__ b1, const bf16_t* __restrict__ W3, int ld3, const float* __restrict__ b3,
+    const float* __restrict__ ret, const float* __restrict__ M0, const float* __restrict__ c0, const bf16_t* __restrict__ M2,
+    int ldm2, const float* __restrict__ c2, const bf16_t* __restrict__ M4, int ldm4, const float* __restrict__ c4,
+    const float* __restrict__ mask, int force_zero, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ out2, int B, int A,
+    int dim, int act) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+  const int H1 = 4 * dim, lde = dim + 8, ldh = H1 + 8;
+  bf16_t* Ein = (bf16_t*)esm;                       // [16][dim + 8]
+  bf16_t* Hs = Ein + 16 * lde;                      // [16][4 dim + 8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int which = blockIdx.y, N = B * A, r0 = blockIdx.x * 16;
+  const bf16_t* Wa = which ? M2 : W1;
+  const int lda = which ? ldm2 : ld1;
+  const float* ba = which ? c2 : b1;
+  const bf16_t* Wb = which ? M4 : W3;
+  const int ldb = which ? ldm4 : ld3;
+  const float* bb = which ? c4 : b3;
+  // ---- inputs of the first wide layer
+  const int half = dim >> 1;
+  for (int i = tid; i < 16 * dim; i += 256) {
+    const int rr = i / dim, j = i - rr * dim;
+    const int row = r0 + rr;
+    float v = 0.f;
+    if (row < N) {
+      if (which == 0) {
+        const float arg = (float)ts[row / A] * freq[j < half ? j : j - half];
+        v = j < half ? sinf(arg) : cosf(arg);
+      } else {
+        v = mish_f(M0[j] * ret[row] + c0[j]);
+      }
+    }
+    Ein[rr * lde + j] = (bf16_t)v;
+  }
+  __syncthreads();
+  // ---- hidden = mish(in . Wa^T + ba): 16 x 4 dim, 16-unit tiles dealt out to the waves
+  const int ks1 = dim >> 5;                         // K-steps of 32 (dim is a multiple of 32, at most 128)
+  bf16x8 a1[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (k < ks1) a1[k] = *(const bf16x8*)(Ein + fr * lde + k * 32 + fq * 8);
+  for (int nt = wave; nt < (H1 >> 4); nt += 4) {
+    const bf16_t* wrow = Wa + (size_t)(nt * 16 + fr) * lda + fq * 8;
+    bf16x8 b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < ks1) b[k] = *(const bf16x8*)(wrow + k * 32);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < ks1) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[k], b[k], acc, 0, 0, 0);
+    const float bias = ba[nt * 16 + fr];
+#pragma unroll
+    for (int r = 0; r < 4; r++) Hs[(fq * 4 + r) * ldh + nt * 16 + fr] = (bf16_t)mish_f(acc[r] + bias);
+  }
+  __syncthreads();
+  // ---- out = hidden . Wb^T + bb: 16 x dim
+  const int ks2 = H1 >> 5;
+  for (int nt = wave; nt < (dim >> 4); nt += 4) {
+    const bf16_t* wrow = Wb + (size_t)(nt * 16 + fr) * ldb + fq * 8;
+    const bf16_t* hrow = Hs + fr * ldh + fq * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < ks2; k0 += 4) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { a[k] = *(const bf16x8*)(hrow + (k0 + k) * 32); b[k] = *(const bf16x8*)(wrow + (k0 + k) * 32); }
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], b[k], acc, 0, 0, 0);
+    }
+    const int col = nt * 16 + fr;
+    const float bias = bb[col];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + fq * 4 + r;
+      if (row >= N) continue;
+      float v = acc[r] + bias;
+      if (which) v = force_zero ? 0.f : (mask ? v * mask[row] : v);
+      out[(size_t)row * ldo + which * dim + col] = (bf16_t)(act ? mish_f(v) : v);
+      if (out2) out2[(size_t)row * ldo + which * dim + col] = (bf16_t)(which ? 0.f : (act ? mish_f(v) : v));
+    }
+  }
+}
+
+// dim: a multiple of 32, <= 128 (4 dim is then a multiple of 128).  ret == NULL: no returns branch (the time half only).
+// Weight matrices: bf16 [O, ld] in the GEMM layout (rows 16-byte aligned); biases and the Linear(1, dim) parameters fp32.
+extern "C" int madiff_embed_mlp_fwd(const long* ts, const float* freq, const void* W1, int ld1, const float* b1, const void* W3,
+                                    int ld3, const float* b3, const float* ret, const float* M0, const float* c0, const void* M2,
+                                    int ldm2, const float* c2, const void* M4, int ldm4, const float* c4, const float* mask,
+                                    int force_zero, void* out, int ldo, void* out2, int B, int A, int dim, int act,
+                                    hipStream_t stream) {
+  if (B <= 0 || A <= 0) return 0;
+  if (dim <= 0 || dim % 32 || dim > 128) return 1;
+  if (!ts || !freq || !W1 || !b1 || !W3 || !b3 || !out || ld1 < dim || ld3 < 4 * dim || ld1 % 8 || ld3 % 8) return -1;
+  if (ret && (!M0 || !c0 || !M2 || !c2 || !M4 || !c4 || ldm2 < dim || ldm4 < 4 * dim || ldm2 % 8 || ldm4 % 8)) return -1;
+  if (ldo < (ret ? 2 : 1) * dim) return -1;
+  if (((size_t)W1 % 16) || ((size_t)W3 % 16) || (ret && (((size_t)M2 % 16) || ((size_t)M4 % 16)))) return 1;
+  const size_t sh = (size_t)16 * ((dim + 8) + (4 * dim + 8)) * 2;
+  const dim3 grid((B * A + 15) / 16, ret ? 2 : 1);
+  hipLaunchKernelGGL(embed_mlp_fwd_kernel, grid, dim3(256), sh, stream, ts, freq, (const bf16_t*)W1, ld1, b1, (const bf16_t*)W3,
+                     ld3, b3, ret, M0, c0, (const bf16_t*)M2, ldm2, c2, (const bf16_t*)M4, ldm4, c4, mask, force_zero,
+                     (bf16_t*)out, ldo, (bf16_t*)out2, B, A, dim, act);
+  MADIFF_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int madiff_sinusoid(int dtype, const long* ts, const float* freq, void* out, int ld, int B, int A, int half,
                                hipStream_t stream) {
   if (B <= 0 || A <= 0 || half <= 0 || ld < 2 * half) return -1;

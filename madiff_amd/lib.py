@@ -71,6 +71,8 @@ _SIGS = {
     "madiff_sampler_advance": [_vp, _vp],
     "madiff_mse_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "madiff_mse_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "madiff_embed_mlp_fwd": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i,
+                             _vp, _i, _i, _i, _i, _vp],
     "madiff_sinusoid": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "madiff_act_fwd": [_i, _i, _vp, _vp, _l, _vp],
     "madiff_act_bwd": [_i, _i, _vp, _vp, _vp, _l, _vp],

@@ -140,6 +140,7 @@ class Conv1dBlock(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # temporal.py
 # ------------------------------------------------------------------------------------------------
+EMBED_FUSED = os.environ.get("MADIFF_EMBED_FUSED", "1") != "0"
 RES_BLOCK_NODE = os.environ.get("MADIFF_RES_BLOCK", "1") != "0"
 ATTN_BLOCK_NODE = os.environ.get("MADIFF_ATTN_BLOCK", "1") != "0"
 
@@ -328,6 +329,12 @@ class TemporalUnet(nn.Module):
         dim = self.time_dim
         bsz = time.shape[0]
         dev = time.device
+        if not torch.is_grad_enabled():
+            if self.returns_condition and use_dropout and dropout_mask is None and not force_dropout:
+                dropout_mask = self.mask_dist.sample(sample_shape=(bsz, n_agents, 1))   # the reference's draw (CPU generator)
+            fused = self.embed_fused(time, returns, n_agents, dropout_mask if use_dropout else None, force_dropout)
+            if fused is not None:
+                return fused
         e = ops.sinusoid(time.to(torch.int64).contiguous(), self.time_mlp[0].freq(dev), n_agents)
         l1, l3 = self.time_mlp[1], self.time_mlp[3]
         e = conv_gemm(mish(conv_gemm(e, [l1.weight], [l1.bias], LINEAR, 1)), [l3.weight], [l3.bias], LINEAR, 1)
@@ -358,6 +365,44 @@ class TemporalUnet(nn.Module):
         if pad32(t.shape[1]) != t.shape[1]:
             t = torch.nn.functional.pad(t, (0, pad32(t.shape[1]) - t.shape[1]))
         return t.contiguous()
+
+    def embed_fused(self, time, returns, n_agents, dropout_mask=None, force_dropout=False, act=False, twin=False):
+        """embed() as ONE launch (madiff_embed_mlp_fwd) where that applies: bf16 build, on the GPU, autograd off (the
+        sampler, the evaluator, validation), no env-timestep branch, dim a multiple of 32 up to 128.  None otherwise.
+        act: the result is Mish(embedding) -- what every consumer applies first.  twin: rows [N, 2N) of the result are the
+        classifier-free-guidance twins of rows [0, N): same time half, returns half zero (diffusion.py:195-202)."""
+        dim = self.time_dim
+        if (not EMBED_FUSED or torch.is_grad_enabled() or ops.get_precision() != "bf16" or not time.is_cuda
+                or self.env_ts_condition or dim % 32 or dim > 128):
+            return None
+        bsz = time.shape[0]
+        n = bsz * n_agents
+        l1, l3 = self.time_mlp[1], self.time_mlp[3]
+        W1, W3 = ops._packed([l1.weight], LINEAR, False), ops._packed([l3.weight], LINEAR, False)
+        width = dim * (2 if self.returns_condition else 1)
+        out = torch.empty(n * (2 if twin else 1), pad32(width), dtype=ops.act_dtype(), device=time.device)
+        if out.shape[1] != width:
+            out[:, width:].zero_()
+        ret = m0 = m2w = m4w = M2 = M4 = None
+        if self.returns_condition:
+            assert returns is not None
+            ret = returns.to(torch.float32).permute(0, 2, 1).reshape(n).contiguous()      # "b t a -> (b a)", t == 1
+            m0, m2w, m4w = self.returns_mlp[0], self.returns_mlp[2], self.returns_mlp[4]
+            M2, M4 = ops._packed([m2w.weight], LINEAR, False), ops._packed([m4w.weight], LINEAR, False)
+        mask = None
+        if dropout_mask is not None and self.returns_condition:
+            mask = dropout_mask.to(device=time.device, dtype=torch.float32).reshape(n).contiguous()
+        ts = time.to(torch.int64).contiguous()
+        p = ops._p
+        rc = ops.lib.call_rc(
+            "madiff_embed_mlp_fwd", ts.data_ptr(), self.time_mlp[0].freq(time.device).data_ptr(), W1.data_ptr(), W1.stride(0),
+            l1.bias.data_ptr(), W3.data_ptr(), W3.stride(0), l3.bias.data_ptr(), p(ret),
+            None if m0 is None else m0.weight.data_ptr(), None if m0 is None else m0.bias.data_ptr(), p(M2),
+            0 if M2 is None else M2.stride(0), None if m2w is None else m2w.bias.data_ptr(), p(M4),
+            0 if M4 is None else M4.stride(0), None if m4w is None else m4w.bias.data_ptr(), p(mask), int(bool(force_dropout)),
+            out.data_ptr(), out.stride(0), (out.data_ptr() + n * out.stride(0) * out.element_size()) if twin else None,
+            bsz, n_agents, dim, int(bool(act)), ops._stream())
+        return out if rc == 0 else None
 
     def rtb_blocks(self):
         """The residual blocks in execution order (their Linear(Mish(t_emb)) run as one GEMM per forward)."""
@@ -467,11 +512,13 @@ class SharedConvAttentionDeconv(nn.Module):
             layers += self.self_attn[i].time_layers()
         return blocks, layers, n_live_attn
 
-    def forward_cl(self, xcl, bsz, t_len, temb):
-        """xcl: cl [(b a) t, pad32(F)]; temb: cl [B*A, pad32(E)].  Returns eps fp32 [B, T, A, F]."""
+    def forward_cl(self, xcl, bsz, t_len, temb, temb_act=False):
+        """xcl: cl [(b a) t, pad32(F)]; temb: cl [B*A, pad32(E)] (temb_act: already Mish(embedding), as embed_fused can
+        produce it).  Returns eps fp32 [B, T, A, F]."""
         net, A = self.net, self.n_agents
         blocks, layers, n_attn = self._time_layers()
-        proj_all = conv_gemm(mish(temb), [l.weight for l in layers], [l.bias for l in layers], LINEAR, 1, perm="f32")
+        proj_all = conv_gemm(temb if temb_act else mish(temb), [l.weight for l in layers], [l.bias for l in layers], LINEAR, 1,
+                             perm="f32")
         sizes = [b.out_channels for b in blocks] + [2 * self.self_attn[i].cq + self.self_attn[i].cv for i in range(n_attn)]
         views = ops.split_cols(proj_all, tuple(sizes))
         bproj, aproj = views[: len(blocks)], views[len(blocks):]
@@ -517,6 +564,10 @@ class SharedConvAttentionDeconv(nn.Module):
         conditional pass (use_dropout=False), rows [B, 2B) the unconditional one (force_dropout=True)
         (diffusion.py:187-202).  xcl holds the B conditioned inputs; returns (eps_cond, eps_uncond)."""
         A = self.n_agents
+        both = self.net.embed_fused(time, returns, A, None, False, act=True, twin=True) if env_timestep is None else None
+        if both is not None:          # one launch: both embeddings of the pair, Mish applied
+            out = self.forward_cl(torch.cat((xcl, xcl), dim=0), 2 * bsz, t_len, both, temb_act=True)
+            return out[:bsz], out[bsz:]
         tc = self.net.embed(time, returns, A, False, False, None, env_timestep)
         tu = self.net.embed(time, returns, A, False, True, None, env_timestep)
         out = self.forward_cl(torch.cat((xcl, xcl), dim=0), 2 * bsz, t_len, torch.cat((tc, tu), dim=0))

@@ -384,6 +384,47 @@ def test_posterior_step_device_noise_matches_philox_oracle():
     assert np.abs(out[:4096].cpu().numpy() - O.philox_normal(seed, stream, 1, 4096)).max() < 2e-5
 
 
+@pytest.mark.parametrize("dim,A,B", [(128, 3, 37), (32, 8, 5), (128, 1, 16)])
+def test_fused_embedding_head_matches_separate_launches(dim, A, B):
+    """madiff_embed_mlp_fwd (sinusoid -> time MLP, returns MLP, dropout mask / force_dropout, concatenation: one launch,
+    both wide layers on MFMA) against the same head issued as separate launches (which the reference goldens pin), bf16
+    build, autograd off: plain, masked, forced, and the activated classifier-free-guidance pair."""
+    import torch.nn.functional as F
+    from madiff_amd import modules as M, ops
+    ops.set_precision("bf16")
+    dev = _dev()
+    net = M.TemporalUnet(horizon=8, transition_dim=6, dim=dim, dim_mults=(1, 2), returns_condition=True,
+                         condition_dropout=0.25).to(dev)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g).to(dev) * (1.0 / math.sqrt(max(p_.shape[-1], 1))))
+    ops.params_changed()
+    t = torch.randint(0, 200, (B,), generator=g).to(dev)
+    r = torch.rand(B, 1, A, generator=g).to(dev)
+    mask = (torch.rand(B, A, 1, generator=g) < 0.75).float().to(dev)
+    with torch.no_grad():
+        for kw in (dict(use_dropout=False, force_dropout=False), dict(use_dropout=True, force_dropout=False, dropout_mask=mask),
+                   dict(use_dropout=False, force_dropout=True)):
+            M.EMBED_FUSED = False
+            ref = net.embed(t, r, A, **kw).float()
+            M.EMBED_FUSED = True
+            got = net.embed_fused(t, r, A, kw.get("dropout_mask"), kw["force_dropout"])
+            assert got is not None and got.shape == ref.shape
+            assert rel_err(got.float().cpu(), ref.cpu()) < 2e-2, kw
+            if kw["force_dropout"]:
+                assert float(got[:, dim:2 * dim].abs().max()) == 0.0
+        M.EMBED_FUSED = False
+        tc, tu = net.embed(t, r, A, False, False), net.embed(t, r, A, False, True)
+        M.EMBED_FUSED = True
+        both = net.embed_fused(t, r, A, None, False, act=True, twin=True)
+        want = F.mish(torch.cat((tc, tu), dim=0).float())
+        assert both.shape == want.shape and rel_err(both.float().cpu(), want.cpu()) < 2e-2
+        assert float(both[B * A:, dim:2 * dim].abs().max()) == 0.0
+    # with autograd on the head stays on the differentiable launches
+    assert net.embed_fused(t, r, A) is None
+
+
 def test_sinusoid_and_activations(prec):
     from madiff_amd import modules as M, ops
     from oracle import madiff_oracle as O
