@@ -4,6 +4,11 @@
 // Trajectory tensors keep the reference layout [B, T, A, F] in fp32; the denoiser's internal layout is
 // [(b a), t, Fpad] in the build's storage type.
 #include "common.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 // ---------------------------------------------------------------- pack: [B,T,A,F] f32 -> [(b a) t Fpad]
 // optional add_noise (diffusers DDPMScheduler.add_noise, called at diffusion.py:292) and inpainting
@@ -811,6 +816,18 @@ extern "C" int madiff_capture_join(hipStream_t waiter, hipStream_t waited) {
   if (rc != hipSuccess) return (int)rc;
   if (s1 != hipStreamCaptureStatusActive || s2 != hipStreamCaptureStatusActive || id1 != id2 || g1 != g2) return 1;
   if (n2 == 0) return 0;
+  {
+    // A waiter that already waits for exactly these nodes (same capture) keeps doing so through its own chain of nodes:
+    // adding them again only multiplies edges (the optimizer's per-slice joins made every Adam node depend on the same
+    // six nodes, and gave one data-gradient node 16 successors).
+    static std::mutex mu;
+    static std::map<std::pair<hipStream_t, hipStream_t>, std::pair<unsigned long long, std::vector<hipGraphNode_t>>> joined;
+    std::lock_guard<std::mutex> lock(mu);
+    auto& e = joined[std::make_pair(waiter, waited)];
+    if (e.first == id1 && e.second.size() == n2 && std::equal(e.second.begin(), e.second.end(), d2)) return 0;
+    e.first = id1;
+    e.second.assign(d2, d2 + n2);
+  }
   return (int)hipStreamUpdateCaptureDependencies(waiter, const_cast<hipGraphNode_t*>(d2), n2, hipStreamAddCaptureDependencies);
 }
 extern "C" int madiff_stream_wait_event(hipStream_t stream, void* event) {

@@ -185,7 +185,7 @@ class ResidualTemporalBlock(nn.Module):
         n, _, tl = x.shape
         lin = self.time_mlp[1]
         proj = conv_gemm(mish(rows_to_cl(t)), [lin.weight], [lin.bias], LINEAR, 1, perm="f32")
-        return from_cl(self.forward_cl(to_cl(x), tl, proj), n, tl, self.out_channels)
+        return from_cl(self.forward_cl(to_cl(x), tl, proj[:, :self.out_channels]), n, tl, self.out_channels)
 
 
 class TemporalSelfAttention(nn.Module):
@@ -229,7 +229,7 @@ class TemporalSelfAttention(nn.Module):
         tl = self.time_layers()
         proj = conv_gemm(mish(rows_to_cl(time.reshape(b * a, -1))), [l.weight for l in tl], [l.bias for l in tl],
                          LINEAR, 1, perm="f32")
-        y = self.forward_cl(to_cl(x.reshape(b * a, c, t)), b, a, t, proj)
+        y = self.forward_cl(to_cl(x.reshape(b * a, c, t)), b, a, t, proj[:, :2 * self.cq + self.cv])
         return from_cl(y, b * a, t, c).reshape(b, a, c, t)
 
 

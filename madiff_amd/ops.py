@@ -47,8 +47,16 @@ def _dt() -> int:
     return lib.BF16 if _PRECISION == "bf16" else lib.F32
 
 
+_PAD64 = os.environ.get("MADIFF_PAD64", "1") != "0"
+
+
 def pad32(c: int) -> int:
-    return (c + 31) // 32 * 32
+    """Channel padding of the cl format: a multiple of 32 -- and of 64 up to 128 channels, so that the narrow layers (the
+    trajectory features F = 16 .. 88 of the first convolution and its residual 1x1, the inverse-dynamics input 2F) have a
+    reduction dimension made of whole 64-channel chunks and run on the LDS-DMA kernels instead of the register-staged
+    generic one (6 launches of ~24 us per training step before).  Pad columns are zero; the cost is a few zero columns of
+    the narrowest tensors."""
+    return (c + 63) // 64 * 64 if (c <= 128 and _PAD64) else (c + 31) // 32 * 32
 
 
 _SPLITK_WS: dict = {}          # device index -> (workspace, counters) registered with the library (kept alive here)

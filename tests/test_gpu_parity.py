@@ -147,7 +147,7 @@ def test_denoiser_full_width_vs_reference_golden(golden, prec):
     with torch.no_grad():
         yc = dif.model(x, t, returns=r, use_dropout=False)
         yu = dif.model(x, t, returns=r, use_dropout=False, force_dropout=True)
-        ec, eu = dif.model.forward_guided_pair(__import__("madiff_amd.ops", fromlist=["x"]).pack_traj(x, 32), 2, 24, t, r)
+        ec, eu = dif.model.forward_guided_pair(__import__("madiff_amd.ops", fromlist=["x"]).pack_traj(x, 64), 2, 24, t, r)
     assert rel_err(yc.cpu(), g["spread.y_cond"]) < OUT_TOL[prec]
     assert rel_err(yu.cpu(), g["spread.y_uncond"]) < OUT_TOL[prec]
     assert rel_err(ec.cpu(), g["spread.y_cond"]) < OUT_TOL[prec]        # 2B-batch CFG pair == two separate passes
