@@ -90,9 +90,10 @@ def build(device):
 
 
 KERNEL_DESC = {
-    "conv_taps_bf16_kernel": "conv_taps_bf16_kernel<WM, WT, D> (all-taps k5 implicit-GEMM convolution: forward + data-gradient "
-                             "launches of the stride-1 k5 layers incl. the fused GroupNorm+Mish forward epilogue, both tile instantiations; the "
-                             "data-gradient launches that also run a GroupNorm backward are the <GNB> family)",
+    "conv_taps_bf16_kernel": "conv_taps_bf16_kernel<WM, WT, D, GNB> (all-taps k5 implicit-GEMM convolution, EVERY launch of the "
+                             "template in the step: forward with the fused GroupNorm+Mish epilogue, plain data gradient, and the "
+                             "<GNB> data gradients that run the preceding block's GroupNorm+Mish backward in their epilogue; "
+                             "by_variant splits the two timing labels)",
     "conv_taps_bf16_kernel<GNB>": "conv_taps_bf16_kernel<.., GNB = true> (k5 data gradient with the preceding block's GroupNorm+Mish "
                                   "backward as its epilogue)",
     "gemm_fwd_bf16_kernel": "gemm_fwd_bf16_kernel<OutT, BM, BN, WT, D> (LDS-DMA implicit-GEMM conv/linear: forward + "
@@ -227,6 +228,28 @@ def launch_ranks(n, argv, script=None, check_devices=True, port=None):
     return subprocess.call(cmd, env=env)
 
 
+SAMPLE_GRAPH_DESC = ("the whole K-step loop (2B-batch forward, guidance mix, posterior step with device-side Philox noise, "
+                     "inpainting) captured once and replayed as ONE hipGraph launch per rank after one eager step")
+
+
+def dp1_ms_per_step(args):
+    """ms/step of the DATA-PARALLEL code path at one rank (1-rank RCCL group: bucket events, all-reduce launches on the
+    communication stream, eager fused Adam behind them), measured by a child process running this same file with
+    MADIFF_FORCE_DP=1 after the headline measurement: what the N=1 -> N=2 step of the scaling table pays before any
+    inter-GPU traffic.  None when the child fails."""
+    import subprocess
+    env = dict(os.environ, MADIFF_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 200))
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--no-sample", "--no-cpu", "--workload", args.workload, "--batch", str(args.batch)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)["ms_per_step"]
+    except Exception as e:                           # noqa: BLE001
+        print(f"bench.py: one-rank data-parallel rehearsal failed ({e!r})", file=sys.stderr, flush=True)
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +257,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-dp1", action="store_true", help="skip the one-rank data-parallel rehearsal (extra.dp1_ms_per_step)")
     ap.add_argument("--no-graph", action="store_true", help="single-GPU: issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--sample-batch", type=int, default=1024,
                     help="episodes sampled per GPU (BASELINE.json configs[4]: 8192 episodes over 8 GPUs = 1024 per GPU)")
@@ -401,7 +425,7 @@ def main():
             tf = tps * K_DIFF * 2 * FWD_GF_PER_SAMPLE / 1e3 / world      # model TFLOP/s per GPU (2 forwards per step)
             sample = {"metric": "DDPM sampled trajectories/sec", "value": tps, "unit": "trajectories/s",
                       "workload": WORKLOAD_DESC, "episodes": sb * world, "episodes_per_gpu": sb, "k_steps": K_DIFF,
-                      "guidance": "2B-batch CFG, w=1.2", "graph": "one captured step replayed K-2 times per rank",
+                      "guidance": "2B-batch CFG, w=1.2", "graph": SAMPLE_GRAPH_DESC,
                       "collectives": "none in the loop; one final gather to rank 0 (inside the timed region)",
                       "seconds": sdt, "finite": bool(torch.isfinite(xs).all().item()),
                       "inpainting_exact": bool(torch.equal(xs[:, : HH + 1], cond["x"][:, : HH + 1])),
@@ -416,7 +440,16 @@ def main():
 
     if rank == 0:
         dom = max((k for k in summ if "gemm" in k or "conv_taps" in k), key=lambda k: summ[k]["ms"])   # dominant kernel
-        d = summ[dom]
+        d = dict(summ[dom])
+        by_variant = None
+        if dom.startswith("conv_taps_bf16_kernel"):
+            # one kernel template, two timing labels: report the WHOLE family (forward + data gradient + the <GNB> data
+            # gradients with the GroupNorm-backward prologue), which is also what the PMC traffic record aggregates
+            dom = "conv_taps_bf16_kernel"
+            parts = {k: v for k, v in summ.items() if k.startswith("conv_taps_bf16_kernel")}
+            d = {f: sum(v.get(f, 0.0) for v in parts.values()) for f in ("flops", "ms", "launches")}
+            by_variant = {k: {"launches_per_step": v["launches"] / args.steps, "avg_us": 1e3 * v["ms"] / v["launches"],
+                              "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in parts.items()}
         traffic = load_traffic(dom, d["launches"] / args.steps)
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         kernels = {}
@@ -450,13 +483,15 @@ def main():
                          "traffic": traffic, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                          "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                          "launches_per_step": d["launches"] / args.steps,
-                         "timed_on": timed_on},
+                         "by_variant": by_variant, "timed_on": timed_on},
             "kernels": kernels,
             "model_tflops_per_gpu": 3 * fwd_flops_step * args.steps / dt / 1e12,
             "sample": sample,
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not force_dp and not args.no_dp1:
+            out["extra"] = {"dp1_ms_per_step": dp1_ms_per_step(args)}
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
         dist.destroy_process_group()

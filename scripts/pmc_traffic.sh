@@ -21,7 +21,7 @@ out = {}
 fam = lambda n: re.sub(r"^void ", "", n).split("<")[0].split("(")[0]
 FAMS = ("conv_taps_bf16_kernel", "gemm_fwd_bf16_kernel", "gemm_wgrad_taps8_bf16_kernel", "gemm_wgrad_taps_bf16_kernel",
         "gemm_wgrad_bf16_kernel", "gn_mish_bwd_rb_kernel", "gn_mish_fwd_rb_kernel", "adam_ema_kernel", "attn_fwd_v2_kernel",
-        "attn_bwd_v2_kernel")
+        "attn_bwd_v2_kernel", "attn_fwd_mfma_kernel", "attn_bwd_mfma_kernel")
 def family(name):
     for f in FAMS:
         if f in name:
