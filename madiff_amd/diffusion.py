@@ -255,7 +255,7 @@ class GaussianDiffusion(nn.Module):
         """Denoising steps held by ONE captured graph.  Default: all of them -- the K-step loop is one graph launch
         (diffusion.py:249-263 without the host between steps).  MADIFF_SAMPLE_GRAPH_STEPS=<n> caps it (the graph then holds
         the largest divisor of K below the cap and is replayed K / chunk times; 1 = round 2's one-step graph)."""
-        cap = int(os.environ.get("MADIFF_SAMPLE_GRAPH_STEPS", "0"))
+        cap = int(os.environ.get("MADIFF_SAMPLE_GRAPH_STEPS") or 0)
         if cap <= 0 or cap >= n_steps:
             return n_steps
         return max(d for d in range(1, cap + 1) if n_steps % d == 0)
