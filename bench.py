@@ -250,6 +250,47 @@ def dp1_ms_per_step(args):
         return None
 
 
+def same_box_matmul(device, n_seq=1024, t=6, cin=1024, cout=1024, iters=20):
+    """The vendor library on this box beside the kernel: torch.matmul (hipBLASLt) in bf16 on the im2col-EQUIVALENT dense
+    problem [n_seq*t, 5*cin] x [5*cin, cout] of the largest k5 layer of the headline workload, and this repository's
+    all-taps kernel on the real layer (plain convolution + bias, no GroupNorm epilogue, so both do the same arithmetic;
+    the library is not charged for the im2col it would need).  Both timed as `iters` launches inside one graph replay."""
+    from madiff_amd import ops
+    M, K = n_seq * t, 5 * cin
+    flops = 2.0 * M * K * cout
+
+    def graph_us(fn):
+        for _ in range(3):
+            fn()
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (3 * iters)
+
+    with torch.no_grad():
+        a = torch.randn(M, K, device=device, dtype=torch.bfloat16)
+        b = torch.randn(K, cout, device=device, dtype=torch.bfloat16)
+        lib_us = graph_us(lambda: torch.matmul(a, b))
+        del a, b
+        x = torch.randn(M, cin, device=device).to(torch.bfloat16)
+        w = torch.randn(cout, cin, 5, device=device) / (5 * cin) ** 0.5
+        bias = torch.zeros(cout, device=device)
+        own_us = graph_us(lambda: ops.conv_gemm(x, [w], [bias], ops.CONV5, t))
+    return {"problem": f"k5 conv {cin}->{cout}, {n_seq} sequences x T={t}: [{M}, {K}] x [{K}, {cout}] bf16",
+            "torch_matmul_us": lib_us, "torch_matmul_tflops": flops / lib_us / 1e6,
+            "conv_taps_us": own_us, "conv_taps_tflops": flops / own_us / 1e6}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -490,6 +531,11 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1:
+            try:
+                out["roofline"]["same_box_matmul"] = same_box_matmul(device, n_seq=BATCH * A, t=max(1, T // 4))
+            except Exception as e:                   # noqa: BLE001
+                print(f"bench.py: library comparison failed ({e!r})", file=sys.stderr, flush=True)
         if world == 1 and not force_dp and not args.no_dp1:
             out["extra"] = {"dp1_ms_per_step": dp1_ms_per_step(args)}
         print(json.dumps(out), flush=True)

@@ -13,7 +13,10 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for N, T, ci, co in [(1024, 6, 1024, 1024), (8192, 6, 1024, 1024), (8192, 12, 512, 512), (8192, 24, 128, 128)]:
+SH = [(1024, 6, 1024, 1024), (8192, 6, 1024, 1024), (8192, 12, 512, 512), (8192, 24, 128, 128)]
+if len(sys.argv) > 1:
+    SH = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for N, T, ci, co in SH:
     M = N * T
     x = torch.randn(M, ci, device=dev).to(torch.bfloat16)
     w = torch.randn(co, ci, 5, device=dev) / (ci * 5) ** 0.5

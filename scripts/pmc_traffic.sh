@@ -6,14 +6,14 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-CMD="bench.py --steps 2 --warmup 2 --no-sample --no-cpu --no-graph"
+CMD="bench.py --steps 2 --warmup 2 --no-sample --no-cpu --no-dp1 --no-graph"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $CMD > $OUT/$C.log 2>&1 || { echo "$C pass failed"; tail -5 $OUT/$C.log; exit 1; }
 done
 python3 - <<PY
-import csv, glob, json, collections, re
+import csv, glob, json, collections, os, re
 def collect(counter):
-    f = glob.glob("$OUT/%s/**/*counter_collection.csv" % counter, recursive=True)[0]
+    f = max(glob.glob("$OUT/%s/**/*counter_collection.csv" % counter, recursive=True), key=os.path.getsize)
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
@@ -41,6 +41,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
 kernels = {}
 for f, d in res.items():
     n = d["n"]["FETCH_SIZE"]
+    if n == 0 or d["n"]["WRITE_SIZE"] == 0:     # launched in one pass only (a tuning choice that differed between the runs)
+        continue
     fetch = 2.0 * 1024.0 * d["FETCH_SIZE"] / n      # KB -> bytes, x2: gfx950 tallies 128-byte read requests at 64 bytes
     write = 1024.0 * d["WRITE_SIZE"] / d["n"]["WRITE_SIZE"]
     kernels[f] = {"fetch_bytes": fetch, "write_bytes": write, "bytes_per_launch": fetch + write, "launches_per_step": n / 2.0,

@@ -30,7 +30,11 @@ def timeit(fn, n=20):
 a = torch.randn(4096, 4096, device=dev)
 for _ in range(100):
     a @ a
-for N, T, ci, co in [(192, 6, 1024, 1024), (192, 12, 512, 512), (192, 24, 128, 128), (96, 6, 1024, 1024)]:
+SHAPES = [(192, 6, 1024, 1024), (192, 12, 512, 512), (192, 24, 128, 128), (96, 6, 1024, 1024)]
+if len(sys.argv) > 1:
+    n_ = int(sys.argv[1])
+    SHAPES = [(n_, 6, 1024, 1024), (n_, 6, 512, 1024), (n_, 12, 512, 512), (n_, 12, 128, 512), (n_, 24, 128, 128)]
+for N, T, ci, co in SHAPES:
     M = N * T
     x = torch.randn(M, ci, device=dev).to(torch.bfloat16)
     w = torch.randn(co, ci, 5, device=dev) / (ci * 5) ** 0.5
