@@ -151,13 +151,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
     if (s + D - 1 <= nsteps) wait_vmcnt<(D - 2) * PIECES>();   // stage s landed, D-2 younger stages still in flight
     else wait_vmcnt<0>();                                      // tail: fewer stages are outstanding
     __builtin_amdgcn_s_barrier();
-    if (issued < nsteps) issue_next();                         // into the buffer every wave finished reading in step s-1
     const unsigned char* As = &smem[buf * BUF_BYTES];
     const unsigned char* Ws = As + A_BYTES;
     if (++buf == D) buf = 0;
-#pragma unroll
-    for (int kh = 0; kh < 2; kh++) {
-      bf16x8 a[MI], b[NJ];
+    auto load_frags = [&](bf16x8 (&a)[MI], bf16x8 (&b)[NJ], const int kh) {
 #pragma unroll
       for (int i = 0; i < MI; i++) {
         int ra = wm * (BM / 2) + i * 16 + fr;
@@ -181,12 +178,23 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
           b[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
         }
       }
+    };
+    // the fragment reads of this stage go out FIRST, the next stage's DMA (address arithmetic + 4..8 issue slots) is
+    // issued under their latency: with one workgroup on the CU (small M) nothing else hides either
+    bf16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
+    load_frags(a0, b0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (issued < nsteps) issue_next();                         // into the buffer every wave finished reading in step s-1
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(a1, b1, 1);
 #pragma unroll
-      for (int i = 0; i < MI; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int j = 0; j < NJ; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+      for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
   }
 
   OutT* C = (OutT*)p.C;
