@@ -57,6 +57,21 @@ __device__ __forceinline__ void xcd_remap(int& bx, int& by, int on) {
   by = (xcd >> 2) * bh + local / bw;
 }
 
+// Any grid: workgroups reach the 8 XCDs round-robin in linear order (x fastest), so XCD c runs linear ids c, c + 8, ...
+// Give XCD c a CONTIGUOUS run of the tile order instead (a bijection for every grid size): mode 1 = x fastest inside the
+// run (all row tiles of a column tile meet in one L2: the weight tile is fetched once), mode 2 = y fastest (all column
+// tiles of a row tile meet in one L2: the activation tile is fetched once).
+__device__ __forceinline__ void xcd_chunk_remap(int& bx, int& by, int mode) {
+  if (!mode) return;
+  const int gx = gridDim.x, gy = gridDim.y, n = gx * gy;
+  const int id = bx + gx * by;
+  const int xcd = id & 7, local = id >> 3;
+  const int q = n >> 3, r = n & 7;
+  const int L = xcd * q + (xcd < r ? xcd : r) + local;
+  if (mode == 1) { bx = L % gx; by = L / gx; }
+  else { by = L % gy; bx = L / gy; }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  xcd_chunk_remap(bx, by, p.xcd);
+  const int m0 = bx * BM, n0 = by * BN;
 
   // DMA pieces: one wave instruction moves 1 KB = 8 rows x 8 chunks (16 B) of a 128-byte-row tile.  Wave w issues the
   // pieces for rows [BM/4*w, BM/4*(w+1)) of A and the matching quarter of W.
@@ -364,6 +366,15 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_fwd_bf16
                 (!p.bias || (size_t)p.bias % 16 == 0) &&
                 (!p.rowbias || ((size_t)p.rowbias % 16 == 0 && p.ldrb % 4 == 0));
     if (p.addend && (!p.vec_epi || out_f32 || p.permA > 0)) return 1;      // the addend exists in the vector epilogue only
+  }
+  {   // XCD-aware tile order (common.h xcd_chunk_remap): keep the LARGER operand's tiles together in one L2
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MADIFF_GEMM_XCD"); on = e ? atoi(e) : 1; }
+    const double xb = (double)p.M, wb = (double)p.Npad;            // bytes ~ rows x K on both sides
+    // (measured: mode 1 for weight-heavy small-M layers looks 10 % faster when one layer is launched back to back -- its
+    // weight tiles then stay in "their" L2 from launch to launch -- and is 10 % SLOWER inside the evaluator's real loop,
+    // where every layer's weights arrive cold: 184 -> 205 ms per planning step.  So only the activation-heavy case.)
+    p.xcd = on == 0 ? 0 : (on == 1 ? (xb >= 4 * wb ? 2 : 0) : on - 1);   // MADIFF_GEMM_XCD=2 / 3 force mode 1 / 2
   }
   if (p.wt && out_f32) {     // split-K data gradient: one variant, fp32 atomics
     if (tile != 8) return -1;

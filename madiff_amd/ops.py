@@ -494,6 +494,25 @@ if _TUNE_CACHE:
     atexit.register(lambda: save_tune_cache(_TUNE_CACHE))
 
 
+_TUNE_COLD = os.environ.get("MADIFF_TUNE_COLD", "1") != "0"
+_THRASH: dict = {}
+
+
+def _thrash_l2() -> None:
+    """Between two timed launches of a tuning decision: overwrite 64 MB, twice the chip's L2.  In the real step a layer's
+    weights arrive cold (every layer of the network runs between two uses); five back-to-back launches of ONE layer keep
+    its weight tiles in L2 and flattered the larger tiles: the tuner chose the 192-row tile for the T = 12 layers of the
+    sampler (208 vs 215 us alone) where the 96-row one is 189 vs 232 us inside the loop.  The fill costs every candidate
+    the same."""
+    if not _TUNE_COLD:
+        return
+    dev = torch.cuda.current_device()
+    buf = _THRASH.get(dev)
+    if buf is None:
+        buf = _THRASH[dev] = torch.empty(64 << 20, dtype=torch.uint8, device=f"cuda:{dev}")
+    buf.zero_()
+
+
 def _time_calls(fn, reps: int = 5) -> float:
     """Milliseconds for `reps` calls of fn on the current stream (tuning decisions, never under capture)."""
     fn()
@@ -502,6 +521,7 @@ def _time_calls(fn, reps: int = 5) -> float:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
+            _thrash_l2()
             fn()
         e1.record()
         e1.synchronize()
@@ -527,6 +547,7 @@ def _tuned_tile(sig, candidates, launch) -> int:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
+                _thrash_l2()
                 launch(tile)
             e1.record()
             e1.synchronize()
@@ -646,6 +667,7 @@ def _wgrad(dy, x, x2, csplit, M, cin, spec: ConvSpec, t_out, t_in, dW, nout, acc
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
+                    _thrash_l2()
                     launch(scratch, 1, tile, splits)
                 e1.record()
                 e1.synchronize()
