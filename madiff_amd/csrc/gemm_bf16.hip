@@ -63,6 +63,31 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
   // DMA pieces: one wave instruction moves 1 KB = 8 rows x 8 chunks (16 B) of a 128-byte-row tile.  Wave w issues the
   // pieces for rows [BM/4*w, BM/4*(w+1)) of A and the matching quarter of W.
   const int pos = lane & 7;
+  // Parity-major rows (p.par: transposed stride-2 maps -- ConvTranspose1d(k4, s2) forward, the strided convolution's
+  // data gradient -- with an even T_out): tile row index m enumerates (parity, sequence, t / 2) instead of (sequence, t).
+  // An output step t takes tap k only when (t + pad - k) is even, so a tile whose rows share one parity needs every
+  // second tap only; the other taps' K-steps multiplied the zero page and are not run at all.  Sums are unchanged bit
+  // for bit (the skipped products were +0).  A tile that straddles the parity boundary runs every tap, as before.
+  const int Th = p.rm.T_out >> 1, half = p.M >> 1;
+  auto row_nt = [&](int m, int& n, int& t) {
+    if (p.par) {
+      const int ph = m >= half ? 1 : 0, q = m - ph * half;
+      n = q / Th;
+      t = 2 * (q - n * Th) + ph;
+    } else {
+      n = m / p.rm.T_out;
+      t = m - n * p.rm.T_out;
+    }
+  };
+  int tap0 = 0, tap_step = 1, ntap = p.taps;
+  if (p.par) {
+    const int lo = m0 >= half ? 1 : 0, hi = (min(m0 + BM, p.M) - 1) >= half ? 1 : 0;
+    if (lo == hi) {
+      tap0 = (lo + p.rm.pad) & 1;
+      tap_step = 2;
+      ntap = (p.taps - tap0 + 1) >> 1;
+    }
+  }
   int a_n[MI], a_t[MI], a_chunk[MI];
   bool a_ok[MI];
 #pragma unroll
@@ -71,9 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
     a_chunk[j] = pos ^ (row & 7);          // source-side swizzle
     int m = m0 + row;
     a_ok[j] = m < p.M;
-    int n = m / p.rm.T_out;
-    a_n[j] = n;
-    a_t[j] = m - n * p.rm.T_out;
+    row_nt(a_ok[j] ? m : 0, a_n[j], a_t[j]);
   }
   constexpr int WP = WT ? 4 : NJ;          // W pieces per wave
   const unsigned char* w_src[WP];
@@ -91,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
     }
   }
   const int spt = p.Cin >> 6;            // K-steps per tap
-  int s_lo = 0, nsteps = spt * p.taps;
+  int s_lo = 0, nsteps = spt * ntap;
   if (p.ksplit > 1) {                    // this workgroup's slice of the K-steps
     const int per = (nsteps + p.ksplit - 1) / p.ksplit;
     s_lo = blockIdx.z * per;
@@ -137,13 +160,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   constexpr int PIECES = MI + WP;        // DMA instructions per wave per stage
   int tap = s_lo / spt, cstep = s_lo - tap * spt;      // position of the NEXT stage to issue
+  tap = tap0 + tap_step * tap;
   tap_rows(tap);
   int issued = 0, ibuf = 0;
   auto issue_next = [&]() {
     issue(ibuf, tap, cstep);
     ++issued;
     if (++ibuf == D) ibuf = 0;
-    if (++cstep == spt) { cstep = 0; ++tap; if (issued < nsteps) tap_rows(tap); }
+    if (++cstep == spt) { cstep = 0; tap += tap_step; if (issued < nsteps) tap_rows(tap); }
   };
 #pragma unroll
   for (int d = 0; d < D - 1; d++)
@@ -222,12 +246,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
         const int n = n0 + wn * WN + cv * 8;
         if (m >= p.M || n >= p.Npad) continue;
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const int seq = m / p.rm.T_out;
-        size_t orow = m;
+        int seq, tt;
+        row_nt(m, seq, tt);
+        const size_t nat = (size_t)seq * p.rm.T_out + tt;      // natural row index (== m unless parity-major)
+        size_t orow = nat;
         if (p.permA > 0) {
-          int t = m - seq * p.permT;
           int b_ = seq / p.permA, a_ = seq - b_ * p.permA;
-          orow = ((size_t)b_ * p.permT + t) * p.permA + a_;
+          orow = ((size_t)b_ * p.permT + tt) * p.permA + a_;
         }
         if (n + 8 <= p.Nout) {
           if (p.bias) {
@@ -260,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
           for (int e = 0; e < 8; e++) v[e] = n + e < p.Nout ? mish_f(v[e]) : 0.f;
         }
         if (p.addend) {                       // (launcher: bf16 output, no row permutation; pad columns of the addend are 0)
-          const bf16x8 ad = *(const bf16x8*)((const bf16_t*)p.addend + (size_t)m * p.lda + n);
+          const bf16x8 ad = *(const bf16x8*)((const bf16_t*)p.addend + nat * p.lda + n);
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] += (float)ad[e];
         }
@@ -284,12 +309,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
     for (int r = 0; r < 4; r++) {
       int m = m0 + wm * (BM / 2) + i * 16 + fq * 4 + r;
       if (m >= p.M) continue;
-      int seq = m / p.rm.T_out;
-      size_t orow = m;
+      int seq, tt;
+      row_nt(m, seq, tt);
+      size_t orow = (size_t)seq * p.rm.T_out + tt;
       if (p.permA > 0) {
-        int t = m - seq * p.permT;
         int b_ = seq / p.permA, a_ = seq - b_ * p.permA;
-        orow = ((size_t)b_ * p.permT + t) * p.permA + a_;
+        orow = ((size_t)b_ * p.permT + tt) * p.permA + a_;
       }
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
@@ -375,6 +400,11 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_gemm_fwd_bf16
     // weight tiles then stay in "their" L2 from launch to launch -- and is 10 % SLOWER inside the evaluator's real loop,
     // where every layer's weights arrive cold: 184 -> 205 ms per planning step.  So only the activation-heavy case.)
     p.xcd = on == 0 ? 0 : (on == 1 ? (xb >= 4 * wb ? 2 : 0) : on - 1);   // MADIFF_GEMM_XCD=2 / 3 force mode 1 / 2
+  }
+  {   // parity-major rows for transposed stride-2 maps (see the kernel)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MADIFF_GEMM_PARITY"); on = e ? atoi(e) : 1; }
+    p.par = on && p.rm.tr && p.rm.stride == 2 && p.rm.T_out % 2 == 0 && p.M % p.rm.T_out == 0 && p.taps >= 2;
   }
   if (p.wt && out_f32) {     // split-K data gradient: one variant, fp32 atomics
     if (tile != 8) return -1;

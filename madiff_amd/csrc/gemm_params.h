@@ -28,6 +28,7 @@ struct GemmFwdParams {
   int ksplit;                        // > 1: gridDim.z slices of the K-steps combine with fp32 atomics (fp32 C, pre-zeroed)
   const void* addend; int lda;       // bf16 [M, lda] added to the result after the activation (vector epilogues only), or null
   int xcd;                           // 1: XCD-aware workgroup -> tile map (common.h xcd_remap), all-taps kernel
+  int par;                           // per-tap LDS-DMA kernel, tr = 1 / stride 2: output rows enumerated parity-major (see gemm_bf16.hip)
   // all-taps kernel, reduction split for layers with few output tiles (small batches): gridDim.z = cks slices of the channel
   // chunks; every slice stores its partial tile to ws, the LAST workgroup to arrive (ticket in ws_cnt[tile], reset by it)
   // sums the partials in slice order and runs the epilogue.  ws / ws_cnt: the workspace registered with

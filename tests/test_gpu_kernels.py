@@ -85,7 +85,8 @@ def test_conv_gemm_fwd_bwd(prec, case):
         assert rel_err(a.cpu(), b.cpu()) < TOL[prec] * (3 if prec == "bf16" else 1), name
 
 
-@pytest.mark.parametrize("case", ["conv5", "conv5_t6_tiles", "conv5_t12_tiles", "conv5_t24", "conv5_t8", "down", "up", "conv1_ragged"])
+@pytest.mark.parametrize("case", ["conv5", "conv5_t6_tiles", "conv5_t12_tiles", "conv5_t24", "conv5_t8", "down", "up", "down_parity",
+                                  "up_parity", "conv1_ragged"])
 def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
     """Every output tile of the LDS-DMA kernel gives bit-identical results (forward), and the data gradient computed
     straight from the forward weight layout (transposing LDS reads) matches autograd, for each of its tiles."""
@@ -97,7 +98,10 @@ def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
     cfgs = {"conv5": (9, 6, 192, 128, ops.CONV5), "conv5_t6_tiles": (75, 6, 128, 128, ops.CONV5),
             "conv5_t12_tiles": (37, 12, 64, 128, ops.CONV5), "conv5_t24": (7, 24, 128, 192, ops.CONV5),
             "conv5_t8": (13, 8, 64, 64, ops.CONV5), "down": (5, 12, 64, 256, ops.DOWN), "up": (7, 6, 128, 128, ops.UP),
-            "conv1_ragged": (11, 7, 320, 192, ops.CONV1)}
+            "conv1_ragged": (11, 7, 320, 192, ops.CONV1),
+            # transposed stride-2 maps with several tiles per output parity (parity-major rows: tiles of one parity skip
+            # every second tap, the tile that straddles the parity boundary runs them all)
+            "down_parity": (41, 12, 64, 128, ops.DOWN), "up_parity": (41, 6, 64, 128, ops.UP)}
     N, T, Cin, Co, spec = cfgs[case]
     k = spec.taps
     x = _q(_rand(N, Cin, T, seed=1), "bf16").to(dev).requires_grad_(True)
