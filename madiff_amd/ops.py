@@ -484,6 +484,16 @@ def save_tune_cache(path: str) -> None:
     os.replace(tmp, path)
 
 
+# Packaged defaults (madiff_amd/tune_gfx950.json, written by scripts/make_tune_defaults.sh from the best of several
+# freshly tuned bench runs): read when no MADIFF_TUNE_CACHE is named, never written; shapes they do not hold are tuned on
+# first use as usual.  MADIFF_TUNE_DEFAULTS=0 ignores them.
+_TUNE_DEFAULTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_gfx950.json")
+if not _TUNE_CACHE and os.environ.get("MADIFF_TUNE_DEFAULTS", "1") != "0" and os.path.exists(_TUNE_DEFAULTS):
+    try:
+        load_tune_cache(_TUNE_DEFAULTS)
+    except (OSError, ValueError, SyntaxError):
+        pass
+
 if _TUNE_CACHE:
     import atexit
     if os.path.exists(_TUNE_CACHE):
