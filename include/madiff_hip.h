@@ -40,6 +40,15 @@ int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, int ldx2, in
                             const void* W, int ldw, int Nout, const float* bias, void* Y, int ldy, void* out, int ldo,
                             const float* gamma, const float* beta, float* mean, float* rstd, int G, float eps, int mode,
                             const float* rowbias, int ldrb, const void* res, int ldr, int variant, madiff_stream_t stream);
+/* The same with a per-channel vector next to the row bias (mode 1: + rowbias[n, c] + rowvec[c]; rowvec fp32 [Nout],
+ * 16-byte aligned, or NULL).  Replaces, in the sampling loop only (diffusion.py:214-275 calling temporal.py:231-262,197):
+ * every trajectory of the batch is at the same diffusion step there, so the time half of each block's
+ * Linear(Mish(t_emb)) is one vector per step and the returns half is constant over the K steps. */
+int madiff_conv_gn_mish_fwd_rv(const void* X, int ldx, const void* X2, int ldx2, int Csplit, int M, int Cin, int T,
+                               const void* W, int ldw, int Nout, const float* bias, void* Y, int ldy, void* out, int ldo,
+                               const float* gamma, const float* beta, float* mean, float* rstd, int G, float eps, int mode,
+                               const float* rowbias, int ldrb, const void* res, int ldr, int variant, const float* rowvec,
+                               madiff_stream_t stream);
 
 /* Graph-external events (no counterpart in the reference, which has neither graphs nor data parallelism): a record
  * issued on a capturing stream becomes an event-record node of the hipGraph, so a stream outside the graph (the RCCL

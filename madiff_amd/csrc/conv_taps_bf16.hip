@@ -59,6 +59,7 @@ struct GnEpi {
   int write_y;                                // 1: also store the pre-norm conv output to p.C (needed by backward)
   int mode;                                   // 0 plain, 1 + rowbias[n, c], 2 + res[(n,t), c]
   const float* rowbias; int ldrb;
+  const float* rowvec;                        // mode 1: + rowvec[c] as well (one vector for every sequence), or null
   const bf16_t* res; int ldr;
   int G, gv_log2;                             // groups; log2(16-byte... 8-channel vectors per group)
   float eps;
@@ -405,6 +406,10 @@ __global__ __launch_bounds__(WM * 128) void conv_taps_bf16_kernel(GemmFwdParams 
       const bool live = sq < spt && n < n_seq;
 #pragma unroll
       for (int e = 0; e < 8; e++) rb[sl][e] = (live && ge.mode == 1) ? ge.rowbias[(size_t)n * ge.ldrb + c0 + e] : 0.f;
+      if (ge.rowvec) {                       // (wave-uniform)
+#pragma unroll
+        for (int e = 0; e < 8; e++) rb[sl][e] += ge.rowvec[c0 + e];
+      }
       if (ge.mode == 2) {
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
@@ -798,9 +803,11 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_bf1
 // covered (the caller then runs the convolution and madiff_gn_mish_fwd separately).
 extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_bf16(
     const void* params, int variant, void* out, int ldo, const float* gamma, const float* beta, float* mean, float* rstd, int G,
-    float eps, int mode, const float* rowbias, int ldrb, const void* res, int ldr, int write_y, hipStream_t stream) {
+    float eps, int mode, const float* rowbias, int ldrb, const void* res, int ldr, int write_y, const float* rowvec,
+    hipStream_t stream) {
   GemmFwdParams p = *(const GemmFwdParams*)params;
   const int BM = variant == 1 ? 96 : 192;
+  if (rowvec && (mode != 1 || ((size_t)rowvec % 16))) return -1;
   const int T = p.rm.T_out;
   if (variant == 2 && p.Cin % 128) return 1;
   if (p.wt || p.taps != 5 || p.rm.stride != 1 || p.rm.tr != 0 || p.rm.pad != 2 || p.rm.T_in != T || T > 32 || p.permA > 0 ||
@@ -824,6 +831,7 @@ extern "C" __attribute__((visibility("hidden"))) int madiff_launch_conv_taps_gn_
   GnEpi ge;
   ge.gamma = gamma; ge.beta = beta; ge.mean = mean; ge.rstd = rstd; ge.out = (bf16_t*)out; ge.ldo = ldo;
   ge.write_y = write_y ? 1 : 0; ge.mode = mode; ge.rowbias = rowbias; ge.ldrb = ldrb; ge.res = (const bf16_t*)res; ge.ldr = ldr;
+  ge.rowvec = rowvec;
   ge.G = G; ge.gv_log2 = gl; ge.eps = eps;
   const int spt = BM / T, rows_used = spt * T;
   const int n_seq = p.M / T;

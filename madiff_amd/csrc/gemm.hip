@@ -347,7 +347,7 @@ extern "C" int madiff_launch_conv_taps_bf16(const void* params, int out_f32, int
 extern "C" int madiff_launch_conv_taps_gn_bf16(const void* params, int variant, void* out, int ldo, const float* gamma,
                                                const float* beta, float* mean, float* rstd, int G, float eps, int mode,
                                                const float* rowbias, int ldrb, const void* res, int ldr, int write_y,
-                                               hipStream_t stream);
+                                               const float* rowvec, hipStream_t stream);
 
 // MADIFF_GEMM_IMPL=0 forces the generic register-staged kernel for bf16 too (A/B timing, debugging)
 static int use_dma_kernel() {
@@ -509,11 +509,27 @@ extern "C" int madiff_gemm_fwd(int dtype, int out_f32, const void* X, int ldx, c
 // residual branch, temporal.py:200).  Y (pre-norm conv output, bf16 [M, ldy]) is what backward needs; pass Y = NULL
 // under no_grad to skip that write.  mean / rstd [M/T * G] may be NULL together with Y.  variant: 0 = 192-row tile,
 // 1 = 96-row tile.  Returns 1 when the layer is not covered (caller: madiff_gemm_fwd + madiff_gn_mish_fwd).
+// madiff_conv_gn_mish_fwd_rv: the same with rowvec [Nout] fp32 (mode 1 only, 16-byte aligned, or NULL) added next to the
+// row bias: + rowbias[n, c] + rowvec[c].  For the sampler, where the time half of Linear(Mish(t_emb)) is ONE vector per
+// denoising step (every trajectory of the batch is at the same step) and the returns half is constant over the K steps.
+extern "C" int madiff_conv_gn_mish_fwd_rv(const void* X, int ldx, const void* X2, int ldx2, int Csplit, int M, int Cin, int T,
+                                          const void* W, int ldw, int Nout, const float* bias, void* Y, int ldy, void* out,
+                                          int ldo, const float* gamma, const float* beta, float* mean, float* rstd, int G,
+                                          float eps, int mode, const float* rowbias, int ldrb, const void* res, int ldr,
+                                          int variant, const float* rowvec, hipStream_t stream);
 extern "C" int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, int ldx2, int Csplit, int M, int Cin, int T,
                                        const void* W, int ldw, int Nout, const float* bias, void* Y, int ldy, void* out,
                                        int ldo, const float* gamma, const float* beta, float* mean, float* rstd, int G,
                                        float eps, int mode, const float* rowbias, int ldrb, const void* res, int ldr,
                                        int variant, hipStream_t stream) {
+  return madiff_conv_gn_mish_fwd_rv(X, ldx, X2, ldx2, Csplit, M, Cin, T, W, ldw, Nout, bias, Y, ldy, out, ldo, gamma, beta, mean,
+                                    rstd, G, eps, mode, rowbias, ldrb, res, ldr, variant, nullptr, stream);
+}
+extern "C" int madiff_conv_gn_mish_fwd_rv(const void* X, int ldx, const void* X2, int ldx2, int Csplit, int M, int Cin, int T,
+                                          const void* W, int ldw, int Nout, const float* bias, void* Y, int ldy, void* out,
+                                          int ldo, const float* gamma, const float* beta, float* mean, float* rstd, int G,
+                                          float eps, int mode, const float* rowbias, int ldrb, const void* res, int ldr,
+                                          int variant, const float* rowvec, hipStream_t stream) {
   if (M <= 0 || Nout <= 0) return 0;
   if (!use_dma_kernel()) return 1;
   if (T <= 0 || Cin <= 0 || M % T || ldw < 5 * Cin || (ldw * 2) % 16 || (ldx * 2) % 16 || variant < 0 || variant > 2) return -1;
@@ -527,7 +543,7 @@ extern "C" int madiff_conv_gn_mish_fwd(const void* X, int ldx, const void* X2, i
   p.C = Y; p.ldc = ldy; p.act = 0; p.permT = 0; p.permA = 0;
   p.wt = 0; p.wtap = 0; p.wcols = 0; p.ksplit = 0; p.vec_epi = 1; p.addend = nullptr; p.lda = 0; p.xcd = xcd_on(); attach_ws(p, stream);
   return madiff_launch_conv_taps_gn_bf16(&p, variant, out, ldo, gamma, beta, mean, rstd, G, eps, mode, rowbias, ldrb, res,
-                                         ldr, Y != nullptr, stream);
+                                         ldr, Y != nullptr, rowvec, stream);
 }
 
 extern "C" int madiff_gemm_dgrad_wt_add(const void* dY, int ldy, int M, int Kred, int taps, int T_out, int T_in, int stride,

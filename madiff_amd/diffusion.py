@@ -233,7 +233,7 @@ class GaussianDiffusion(nn.Module):
         if isinstance(self.model, SharedConvAttentionDeconv):
             xcl = ops.pack_traj(x, pad32(x.shape[-1]))
             if self.returns_condition:
-                ec, eu = self.model.forward_guided_pair(xcl, bsz, t_len, st["ts"], returns, env_ts)
+                ec, eu = self.model.forward_guided_pair(xcl, bsz, t_len, st["ts"], returns, env_ts, proj_R=st.get("R"))
             else:
                 temb = self.model.net.embed(st["ts"], None, self.n_agents, False, False, None, env_ts)
                 ec, eu = self.model.forward_cl(xcl, bsz, t_len, temb), None
@@ -334,6 +334,14 @@ class GaussianDiffusion(nn.Module):
         elif rng_host is not None:
             st["rng"].copy_(rng_host)
         reset()
+        # the returns half of every time projection is constant over the K steps: once per call (modules.proj_static)
+        if isinstance(self.model, SharedConvAttentionDeconv) and self.returns_condition and returns_s is not None \
+                and env_ts_s is None:
+            R = self.model.proj_static(returns_s, batch_size)
+            if R is not None and st.get("R") is not None:
+                st["R"].copy_(R)                                   # (the captured loop reads this buffer)
+            elif graph is None:
+                st["R"] = R
         chain = [st["x"].clone()] if return_diffusion else None
         if use_graph and n_steps > 1:
             if graph is None:

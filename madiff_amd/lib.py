@@ -29,6 +29,8 @@ _SIGS = {
     "madiff_capture_join": [_vp, _vp],
     "madiff_conv_gn_mish_fwd": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i,
                                 _f, _i, _vp, _i, _vp, _i, _i, _vp],
+    "madiff_conv_gn_mish_fwd_rv": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i,
+                                   _f, _i, _vp, _i, _vp, _i, _i, _vp, _vp],
     "madiff_gemm_tile_count": [],
     "madiff_set_splitk_workspace": [_vp, _l, _vp, _i],
     "madiff_splitk_slots_used": [],

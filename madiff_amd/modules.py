@@ -140,6 +140,8 @@ class Conv1dBlock(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # temporal.py
 # ------------------------------------------------------------------------------------------------
+PROJ_SPLIT = os.environ.get("MADIFF_PROJ_SPLIT", "1") != "0"
+PROJ_SPLIT_MIN_SEQ = int(os.environ.get("MADIFF_PROJ_SPLIT_MIN_SEQ", "512"))
 EMBED_FUSED = os.environ.get("MADIFF_EMBED_FUSED", "1") != "0"
 RES_BLOCK_NODE = os.environ.get("MADIFF_RES_BLOCK", "1") != "0"
 ATTN_BLOCK_NODE = os.environ.get("MADIFF_ATTN_BLOCK", "1") != "0"
@@ -512,15 +514,62 @@ class SharedConvAttentionDeconv(nn.Module):
             layers += self.self_attn[i].time_layers()
         return blocks, layers, n_live_attn
 
-    def forward_cl(self, xcl, bsz, t_len, temb, temb_act=False):
+    # ---- sampling loop only (diffusion.py:214-275): every trajectory of the batch is at the SAME diffusion step, so with
+    # e = [time_mlp(t) | returns_mlp(r_n)] the projection  W Mish(e) + b  of all 21 time layers splits into
+    #   v_t = W [Mish(time_mlp(t)) | 0] + b     one vector per denoising step                      (proj_step)
+    #   R_n = W [0 | Mish(returns_mlp(r_n))]    one row per sequence, constant over the K steps    (proj_static)
+    # and the consumers add  R[n, c] + v_t[c]  (ops.rowvec_of).  The [2 B A, 10496] fp32 projection GEMM of every step
+    # (108 us and 258 MB written per step at 1024 episodes) becomes a one-row GEMM.
+    def proj_static(self, returns, bsz):
+        """R for the classifier-free-guidance pair batch (rows [0, N) conditional, [N, 2N) unconditional = zeros), with the
+        q/k/v convolution biases of the attention layers folded in (the per-step vector takes their bias operand).  None
+        when the split does not apply (then forward_guided_pair runs the one-GEMM form)."""
+        net, A = self.net, self.n_agents
+        if (not PROJ_SPLIT or torch.is_grad_enabled() or not net.returns_condition or returns is None
+                or 2 * bsz * A < PROJ_SPLIT_MIN_SEQ):
+            return None
+        both = net.embed_fused(torch.zeros(bsz, dtype=torch.int64, device=returns.device), returns, A, None, False, act=True,
+                               twin=True)
+        if both is None:
+            return None
+        both[:, : net.time_dim].zero_()                      # the returns half only
+        blocks, layers, n_attn = self._time_layers()
+        R = conv_gemm(both, [l.weight for l in layers], [], LINEAR, 1, perm="f32")
+        off = sum(b.out_channels for b in blocks)
+        for i in range(n_attn):
+            a = self.self_attn[i]
+            w = 2 * a.cq + a.cv
+            R[:, off:off + w] += torch.cat((a.query_layer.bias, a.key_layer.bias, a.value_layer.bias)).detach()
+            off += w
+        return R
+
+    def proj_step(self, time):
+        """v_t fp32 [1, pad32(total)] for the step all of `time` holds (graph-capturable: reads time[0] on the device)."""
+        net = self.net
+        one = net.embed_fused(time[:1], torch.zeros(1, 1, 1, device=time.device), 1, None, True, act=True, twin=False)
+        if one is None:
+            return None
+        _, layers, _ = self._time_layers()
+        return conv_gemm(one, [l.weight for l in layers], [l.bias for l in layers], LINEAR, 1, perm="f32")
+
+    def forward_cl(self, xcl, bsz, t_len, temb, temb_act=False, proj=None):
         """xcl: cl [(b a) t, pad32(F)]; temb: cl [B*A, pad32(E)] (temb_act: already Mish(embedding), as embed_fused can
-        produce it).  Returns eps fp32 [B, T, A, F]."""
+        produce it), or proj = (R, v_t) from proj_static / proj_step instead of temb.  Returns eps fp32 [B, T, A, F]."""
         net, A = self.net, self.n_agents
         blocks, layers, n_attn = self._time_layers()
-        proj_all = conv_gemm(temb if temb_act else mish(temb), [l.weight for l in layers], [l.bias for l in layers], LINEAR, 1,
-                             perm="f32")
         sizes = [b.out_channels for b in blocks] + [2 * self.self_attn[i].cq + self.self_attn[i].cv for i in range(n_attn)]
+        if proj is not None:
+            proj_all, vec = proj
+            assert not torch.is_grad_enabled() and proj_all.shape[0] == bsz * A
+        else:
+            proj_all = conv_gemm(temb if temb_act else mish(temb), [l.weight for l in layers], [l.bias for l in layers],
+                                 LINEAR, 1, perm="f32")
         views = ops.split_cols(proj_all, tuple(sizes))
+        if proj is not None:
+            off = 0
+            for vw, sz in zip(views, sizes):
+                vw._madiff_rowvec = vec[0, off:off + sz]
+                off += sz
         bproj, aproj = views[: len(blocks)], views[len(blocks):]
         bi = 0
         h, t = xcl, t_len
@@ -559,11 +608,17 @@ class SharedConvAttentionDeconv(nn.Module):
                               force_dropout, dropout_mask, env_timestep)
         return self.forward_cl(PackTraj.apply(x.to(torch.float32)), bsz, t_len, temb)
 
-    def forward_guided_pair(self, xcl, bsz, t_len, time, returns, env_timestep=None):
+    def forward_guided_pair(self, xcl, bsz, t_len, time, returns, env_timestep=None, proj_R=None):
         """Classifier-free-guidance pair as ONE 2B batch (weights are read once): rows [0, B) are the
         conditional pass (use_dropout=False), rows [B, 2B) the unconditional one (force_dropout=True)
         (diffusion.py:187-202).  xcl holds the B conditioned inputs; returns (eps_cond, eps_uncond)."""
         A = self.n_agents
+        if proj_R is not None and env_timestep is None:          # sampler: returns half precomputed, time half one vector
+            vec = self.proj_step(time)
+            self.last_proj_split = vec is not None             # (tests)
+            if vec is not None:
+                out = self.forward_cl(torch.cat((xcl, xcl), dim=0), 2 * bsz, t_len, None, proj=(proj_R, vec))
+                return out[:bsz], out[bsz:]
         both = self.net.embed_fused(time, returns, A, None, False, act=True, twin=True) if env_timestep is None else None
         if both is not None:          # one launch: both embeddings of the pair, Mish applied
             out = self.forward_cl(torch.cat((xcl, xcl), dim=0), 2 * bsz, t_len, both, temb_act=True)

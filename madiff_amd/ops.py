@@ -882,7 +882,11 @@ def _conv_forward(x, x2, rowbias, spec: ConvSpec, t_in: int, act: int, perm, wei
     t_out = spec.out_len(t_in)
     M = n_seq * t_out
     W = _packed(weights, spec, False)
-    if len(biases) == 0:
+    rv = rowvec_of(rowbias)
+    if rv is not None:        # per-step vector beside the row bias: it takes the bias operand (whoever set it folded the
+        bias = rv             # layer's own biases into the row-bias matrix, see SharedConvAttentionDeconv.proj_static)
+        assert rv.dtype == torch.float32 and rv.is_contiguous() and rv.numel() >= osum
+    elif len(biases) == 0:
         bias = None
     elif len(biases) == 1:
         bias = biases[0]
@@ -1137,6 +1141,9 @@ def conv_gemm(x, weights, biases, spec: ConvSpec, t_in: int, x2=None, rowbias=No
 
 def _gn_forward(y, gamma, beta, rowbias, res, n_seq, t, C, G):
     _chk_cl(y)
+    rv = rowvec_of(rowbias)
+    if rv is not None:                         # the standalone kernels take one row bias: form it (rare: unfused layers)
+        rowbias = rowbias + rv[: rowbias.shape[1]]
     cpad = y.shape[1]
     out = torch.empty_like(y)
     stats = torch.empty(2, n_seq * G, dtype=torch.float32, device=y.device)
@@ -1348,13 +1355,17 @@ def _conv_block_fused(x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w,
     if res is not None:
         _chk_cl(res)
 
+    rv = rowvec_of(rowbias)
+    if rv is not None:
+        assert rv.dtype == torch.float32 and rv.is_contiguous() and rv.numel() >= O and not need_y
+
     def launch(variant):
-        return lib.call_rc("madiff_conv_gn_mish_fwd", x.data_ptr(), x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0),
+        return lib.call_rc("madiff_conv_gn_mish_fwd_rv", x.data_ptr(), x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0),
                            c1, M, cin, t_in, W.data_ptr(), W.stride(0), O, _p(b), _p(y), O, out.data_ptr(), O,
                            gamma.data_ptr(), beta.data_ptr(), None if stats is None else stats[0].data_ptr(),
                            None if stats is None else stats[1].data_ptr(), G, 1e-5, mode, _p(rowbias),
                            0 if rowbias is None else rowbias.stride(0), _p(res), 0 if res is None else res.stride(0), variant,
-                           _stream())
+                           _p(rv), _stream())
 
     sig = ("convgn", M, cin, O, t_in, G, mode, need_y, x2 is not None)
     if _AUTOTUNE and _TUNE.get(sig + ("use",)) is False:      # measured: convolution + standalone GroupNorm is faster for this shape
@@ -1714,6 +1725,12 @@ class _GradHolder:
         if self.buf is None:          # not zero-filled: SplitCols.backward defines every column nobody wrote
             self.buf = torch.empty(self.n, self.total, dtype=self.dtype, device=self.device)
         return self.buf[:, off:off + width]
+
+
+def rowvec_of(t):
+    """A per-channel fp32 vector that goes with a row-bias tensor (set by the sampler's per-step time projection,
+    modules.SharedConvAttentionDeconv.forward_cl(proj=...)): consumers add rowbias[n, c] + rowvec[c].  None otherwise."""
+    return None if t is None else getattr(t, "_madiff_rowvec", None)
 
 
 def grad_slot(t):

@@ -504,6 +504,53 @@ def test_whole_loop_graph_is_one_launch_and_matches_eager(prec):
         del os.environ["MADIFF_SAMPLE_GRAPH_STEPS"]
 
 
+def test_sampler_split_time_projection_matches_one_gemm():
+    """Sampling loop: the projection of all time layers as (one row per sequence, constant over the K steps) + (one vector
+    per step) (modules.proj_static / proj_step, the fused conv+GroupNorm launch taking rowbias[n, c] + rowvec[c], the
+    q/k/v GEMM taking the vector as its bias) against the one-GEMM-per-step form: same draws, eager and whole-loop graph."""
+    from madiff_amd import modules as M, ops
+    ops.set_precision("bf16")
+    dev = torch.device("cuda:0")
+    A, Tt, Fd, hh = SHAPES["spread"]
+    K = 12
+    dif, act = build("spread", 32, K)
+    batch = O.synthetic_batch(5, Tt, A, Fd, act, hh, False, 0, seed=29)
+    cond = {k: v.to(dev) for k, v in batch["cond"].items()}
+    ret = batch["returns"].to(dev)
+    x_init = 0.5 * T(O.closed_form_normal("ps.0", (5, Tt, A, Fd)), dev)
+    z = T(O.closed_form_normal("ps.z", (K, 5, Tt, A, Fd)), dev)
+    old = (M.PROJ_SPLIT, M.PROJ_SPLIT_MIN_SEQ)
+    try:
+        M.PROJ_SPLIT, M.PROJ_SPLIT_MIN_SEQ = True, 0
+        # one guided forward: the two forms of the projection agree to fp32 rounding, the outputs to bf16 roundings
+        net = dif.model
+        with torch.no_grad():
+            tt = torch.full((5,), 7, dtype=torch.int64, device=dev)
+            xcl = ops.pack_traj(x_init.contiguous(), ops.pad32(Fd))
+            R = net.proj_static(ret, 5)
+            v = net.proj_step(tt)
+            both = net.net.embed_fused(tt, ret, A, None, False, act=True, twin=True)
+            blocks, layers, _ = net._time_layers()
+            full = ops.conv_gemm(both, [l.weight for l in layers], [l.bias for l in layers], M.LINEAR, 1, perm="f32")
+            nb = sum(b.out_channels for b in blocks)
+            assert float(((R + v)[:, :nb] - full[:, :nb]).abs().max()) < 2e-6 * float(full.abs().max())
+            ec0, eu0 = net.forward_guided_pair(xcl, 5, Tt, tt, ret)
+            ec1, eu1 = net.forward_guided_pair(xcl, 5, Tt, tt, ret, proj_R=R)
+            assert rel_err(ec1.cpu(), ec0.cpu()) < 2e-2 and rel_err(eu1.cpu(), eu0.cpu()) < 2e-2
+        dif.model.last_proj_split = False
+        eager = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, step_noise=z, use_graph=False)
+        assert dif.model.last_proj_split
+        graph = dif.conditional_sample(cond, returns=ret, verbose=False, x_init=x_init, step_noise=z, use_graph=True)
+        assert dif.last_sample_launches == 1 and torch.equal(graph, eager)
+        # a second call with other returns: the kept graph must see the new returns half
+        ret2 = ret * 0.5 + 0.1
+        g2 = dif.conditional_sample(cond, returns=ret2, verbose=False, x_init=x_init, step_noise=z, use_graph=True)
+        e2 = dif.conditional_sample(cond, returns=ret2, verbose=False, x_init=x_init, step_noise=z, use_graph=False)
+        assert torch.equal(g2, e2) and not torch.equal(g2, graph)
+    finally:
+        M.PROJ_SPLIT, M.PROJ_SPLIT_MIN_SEQ = old
+
+
 def test_ddim_vs_reference_golden(golden):
     from madiff_amd import ops
     ops.set_precision("fp32")
