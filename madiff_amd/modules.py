@@ -168,7 +168,7 @@ class ResidualTemporalBlock(nn.Module):
         chain_out / chain_in: the ops.ChainTag two consecutive blocks share when this block's output feeds the next block
         only / this block's input is the previous block's output and nobody else's (the caller guarantees it)."""
         b0, b1 = self.blocks
-        if RES_BLOCK_NODE and b0.spec is CONV5 and b1.spec is CONV5:        # the whole block as one autograd node
+        if RES_BLOCK_NODE and b0.spec == CONV5 and b1.spec == CONV5:        # the whole block as one autograd node
             rc = self.residual_conv if isinstance(self.residual_conv, nn.Conv1d) else None
             return ops.res_block(x, x2, temb_proj, t, b0.n_groups,
                                  (b0.block[0].weight, b0.block[0].bias, b0.block[2].weight, b0.block[2].bias),

@@ -152,6 +152,25 @@ class ConvSpec:
     def __init__(self, kind="linear", taps=1, stride=1, pad=0, tr=0):
         self.kind, self.taps, self.stride, self.pad, self.tr = kind, taps, stride, pad, tr
 
+    # Compared BY VALUE: modules keep a spec as an attribute, and copy.deepcopy(model) -- how the reference makes its EMA
+    # model (utils/training.py:57) -- or unpickling a whole module gives them a new object.  Round 3 found the identity test
+    # `spec is CONV5` silently keeping every deep-copied model (i.e. every EMA sampler after training) off the fused
+    # conv+GroupNorm launch and the ResBlock node.
+    def _key(self):
+        return (self.kind, self.taps, self.stride, self.pad, self.tr)
+
+    def __eq__(self, other):
+        return isinstance(other, ConvSpec) and self._key() == other._key()
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __hash__(self):
+        return hash(self._key())
+
+    def __deepcopy__(self, memo):
+        return self                      # immutable
+
     def out_len(self, t_in: int) -> int:
         if self.tr:
             return (t_in - 1) * self.stride - 2 * self.pad + self.taps
@@ -1233,7 +1252,7 @@ def _dgrad_gn_bwd_fused(g1, w1, dy1, y0, stats0, geom0, gamma0, beta0, bias0, dr
     channels a multiple of 128, whole groups inside 128 channels, T <= 32).
     want_dh (two consecutive blocks, ChainTag): the convolution is the NEXT block's blocks[0], dh = data gradient + addend
     is stored as well (madiff_conv_dgrad_gn_bwd_chain) and returned as a sixth value."""
-    if not FUSE_DGRAD_GN_BWD or _PRECISION != "bf16" or not dy1.is_cuda or g1.spec is not CONV5:
+    if not FUSE_DGRAD_GN_BWD or _PRECISION != "bf16" or not dy1.is_cuda or g1.spec != CONV5:
         return None
     n_seq, t, C, cpad, G, mode = geom0
     if want_dh and (not FUSE_GNB_CHAIN or mode == 1 or g1.n_seq != n_seq or g1.t_out != t or g1.c1 != g1.cin):
@@ -1330,7 +1349,7 @@ FUSE_CONV_GN = os.environ.get("MADIFF_FUSE_CONV_GN", "1") != "0"
 def _conv_block_fused(x, x2, rowbias, res, spec: ConvSpec, t_in: int, G: int, w, b, gamma, beta, need_y: bool):
     """Conv1dBlock forward as ONE launch (madiff_conv_gn_mish_fwd: the all-taps k5 kernel with the GroupNorm + Mish
     epilogue).  Returns (out, y | None, stats | None, g, geom) or None when the layer is not covered."""
-    if not FUSE_CONV_GN or _PRECISION != "bf16" or spec is not CONV5 or not x.is_cuda:
+    if not FUSE_CONV_GN or _PRECISION != "bf16" or spec != CONV5 or not x.is_cuda:
         return None
     O, I, so, si, st = _strides(spec.kind, w)
     c1 = x.shape[1]
