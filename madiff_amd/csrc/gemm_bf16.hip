@@ -122,22 +122,35 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_bf16_kernel(GemmFwdParams p) 
     if (nsteps <= 0) return;             // uniform for the workgroup
   }
 
-  int a_row[MI];
-  auto tap_rows = [&](int tap) {
+  // Per-lane source pointers of the A pieces for the CURRENT tap (channel 0 of each source; the zero page for rows the tap
+  // takes outside the sequence), formed when the tap changes: a K-step then adds the chunk's byte offset only.  (With one
+  // workgroup on the CU the loop is bound by instruction issue, and the 64-bit row arithmetic was a third of it.)
+  const unsigned char* a_ptr[MI];
+  unsigned a_live = 0;                     // bit j: piece j reads a real row
+  int ptr_tap = -1, ptr_second = -1;       // what a_ptr currently describes
+  auto tap_rows = [&](int tap) { (void)tap; };     // (pointers are formed on demand in issue())
+  auto form_ptrs = [&](int tap, int second) {
+    a_live = 0;
+    const unsigned char* xb = (const unsigned char*)(second ? p.X2 : p.X);
+    const int ld = second ? p.ldx2 : p.ldx;
 #pragma unroll
-    for (int j = 0; j < MI; j++) a_row[j] = a_ok[j] ? map_row(a_n[j], a_t[j], tap, p.rm) : -1;
+    for (int j = 0; j < MI; j++) {
+      const int r = a_ok[j] ? map_row(a_n[j], a_t[j], tap, p.rm) : -1;
+      a_ptr[j] = r >= 0 ? xb + (size_t)r * ld * 2 + a_chunk[j] * 16 : g_zero_page + (lane & 7) * 16;
+      if (r >= 0) a_live |= 1u << j;
+    }
+    ptr_tap = tap; ptr_second = second;
   };
 
   auto issue = [&](int buf, int tap, int cstep) {
     const int c0 = cstep << 6;
-    const unsigned char* xb = (const unsigned char*)p.X;
-    int ld = p.ldx, c = c0;
-    if (c0 >= p.Csplit) { xb = (const unsigned char*)p.X2; ld = p.ldx2; c = c0 - p.Csplit; }
+    const int second = c0 >= p.Csplit ? 1 : 0;
+    if (tap != ptr_tap || second != ptr_second) form_ptrs(tap, second);      // workgroup-uniform, once per tap (and split)
+    const unsigned cb = (unsigned)(second ? c0 - p.Csplit : c0) * 2;
     unsigned char* base = &smem[buf * BUF_BYTES];
 #pragma unroll
     for (int j = 0; j < MI; j++) {
-      const unsigned char* ga = a_row[j] >= 0 ? xb + ((size_t)a_row[j] * ld + c) * 2 + a_chunk[j] * 16
-                                              : g_zero_page + (lane & 7) * 16;
+      const unsigned char* ga = a_ptr[j] + ((a_live >> j) & 1 ? cb : 0u);
       dma16(ga, lds_u32(base + (MI * wave + j) * 1024));
     }
     const size_t wk = WT ? ((size_t)c0 * p.ldw + (size_t)tap * p.wtap) * 2 : ((size_t)tap * p.Cin + c0) * 2;

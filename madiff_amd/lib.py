@@ -12,6 +12,8 @@ import torch  # noqa: F401  (loads torch's bundled libamdhip64 first so this lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmadiff_hip.so")
+# MADIFF_LIB_PATH: another build of the same library (A/B timing of a kernel change on one box; same ABI required)
+LIB_PATH = os.environ.get("MADIFF_LIB_PATH") or LIB_PATH
 
 F32, BF16 = 0, 1
 
