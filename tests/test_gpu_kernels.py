@@ -86,7 +86,7 @@ def test_conv_gemm_fwd_bwd(prec, case):
 
 
 @pytest.mark.parametrize("case", ["conv5", "conv5_t6_tiles", "conv5_t12_tiles", "conv5_t24", "conv5_t8", "down", "up", "down_parity",
-                                  "up_parity", "conv1_ragged"])
+                                  "up_parity", "conv1_ragged", "conv1_xcd"])
 def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
     """Every output tile of the LDS-DMA kernel gives bit-identical results (forward), and the data gradient computed
     straight from the forward weight layout (transposing LDS reads) matches autograd, for each of its tiles."""
@@ -101,7 +101,10 @@ def test_gemm_tile_variants_and_dgrad_from_forward_weights(case):
             "conv1_ragged": (11, 7, 320, 192, ops.CONV1),
             # transposed stride-2 maps with several tiles per output parity (parity-major rows: tiles of one parity skip
             # every second tap, the tile that straddles the parity boundary runs them all)
-            "down_parity": (41, 12, 64, 128, ops.DOWN), "up_parity": (41, 6, 64, 128, ops.UP)}
+            "down_parity": (41, 12, 64, 128, ops.DOWN), "up_parity": (41, 6, 64, 128, ops.UP),
+            # rows >= 4 x columns: the per-tap kernel hands every XCD a contiguous run of the tile order (xcd_chunk_remap);
+            # 1026 rows = 17 / 11 / 9 row tiles x 2..3 column tiles, none a multiple of 8
+            "conv1_xcd": (171, 6, 64, 192, ops.CONV1)}
     N, T, Cin, Co, spec = cfgs[case]
     k = spec.taps
     x = _q(_rand(N, Cin, T, seed=1), "bf16").to(dev).requires_grad_(True)
