@@ -994,7 +994,7 @@ def _conv_backward(g, x, x2, weights, biases, dy, need_dx, need_dx2, need_w, bia
 WGRAD_SIDE_STREAM = os.environ.get("MADIFF_WGRAD_SIDE_STREAM", "1") != "0"
 FUSE_BIAS_WGRAD = os.environ.get("MADIFF_FUSE_BIAS_WGRAD", "1") != "0"
 # parameter-gradient launches go round-robin over this many auxiliary streams (parallel branches of the captured step)
-WGRAD_STREAMS = int(os.environ.get("MADIFF_WGRAD_STREAMS", "4"))
+WGRAD_STREAMS = int(os.environ.get("MADIFF_WGRAD_STREAMS", "8"))
 
 
 def wgrad_branch_name(sink, weights) -> str:
