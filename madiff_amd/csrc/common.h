@@ -48,13 +48,21 @@ __device__ __forceinline__ float mish_grad_f(float x) {
 // instead, so what its L2 fetches from HBM is a quarter of one operand plus half of the other.  Identity when the grid does
 // not divide (gx % 4, gy % 2); MADIFF_XCD_REMAP=0 switches it off through the `on` argument.
 __device__ __forceinline__ void xcd_remap(int& bx, int& by, int on) {
+  // on = 1: columns fastest inside the XCD's block (round 3: the column tiles of a row tile run back to back on one XCD,
+  // so the activation tile is fetched once per XCD; +3 % on the sampler, where a CU runs six tiles per launch);
+  // on = 2: rows fastest (round 2's order, kept for A/B: MADIFF_XCD_REMAP=2)
   const int gx = gridDim.x, gy = gridDim.y;
   if (!on || (gx & 3) || (gy & 1)) return;
   const int id = bx + gx * by;
   const int xcd = id & 7, local = id >> 3;
   const int bw = gx >> 2, bh = gy >> 1;
-  bx = (xcd & 3) * bw + local % bw;
-  by = (xcd >> 2) * bh + local / bw;
+  if (on == 2) {
+    bx = (xcd & 3) * bw + local % bw;
+    by = (xcd >> 2) * bh + local / bw;
+  } else {
+    bx = (xcd & 3) * bw + local / bh;
+    by = (xcd >> 2) * bh + local % bh;
+  }
 }
 
 // Any grid: workgroups reach the 8 XCDs round-robin in linear order (x fastest), so XCD c runs linear ids c, c + 8, ...

@@ -451,7 +451,7 @@ static void attach_ws(GemmFwdParams& p, hipStream_t stream) {
 
 static int xcd_on() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("MADIFF_XCD_REMAP"); v = e ? (atoi(e) != 0) : 1; }
+  if (v < 0) { const char* e = getenv("MADIFF_XCD_REMAP"); v = e ? atoi(e) : 1; }
   return v;
 }
 
