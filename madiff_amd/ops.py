@@ -110,8 +110,14 @@ def wait_stream(waiter, waited) -> None:
     capture, and when `waiter` is about to JOIN the capture, it is the ordinary event record + wait."""
     if waiter.cuda_stream == waited.cuda_stream:
         return
-    if lib.call_rc("madiff_capture_join", waiter.cuda_stream, waited.cuda_stream) == 0:
+    rc = lib.call_rc("madiff_capture_join", waiter.cuda_stream, waited.cuda_stream)
+    if rc == 0:
         return
+    if rc != 1:                        # 1 = the two are not in one capture (the event path below); anything else is a HIP error
+        raise RuntimeError(f"madiff_capture_join failed with HIP error {rc}")
+    if stream_is_capturing(waiter) and not stream_is_capturing(waited):
+        # an event recorded outside a capture must not be waited on from inside it: this runtime aborts the process
+        raise RuntimeError("wait_stream: a capturing stream was asked to wait for a stream outside its capture")
     waiter.wait_stream(waited)
 
 
