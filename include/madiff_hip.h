@@ -69,6 +69,10 @@ int madiff_stream_wait_event(madiff_stream_t stream, void* event);
  * runtime.  Returns 1 (nothing done) when the two streams are not both capturing the same graph.
  * No counterpart in the reference (no graphs there). */
 int madiff_capture_join(madiff_stream_t waiter, madiff_stream_t waited);
+/* 0 = `stream` is not capturing, 1 = capturing, 2 = its capture has been invalidated, < 0 = -hipError_t.  No counterpart in
+ * the reference (launch plumbing of the captured step): lets the host refuse to wait on an invalidated capture, which
+ * this runtime answers by aborting the process. */
+int madiff_stream_capture_status(madiff_stream_t stream);
 
 /* Implicit-GEMM convolution / linear:
  *   C[m, o] = act( sum_{tap, c} X[src(m, tap), c] * W[o, tap*Cin + c] + bias[o] + rowbias[m / T_out, o] )

@@ -830,6 +830,13 @@ extern "C" int madiff_capture_join(hipStream_t waiter, hipStream_t waited) {
   }
   return (int)hipStreamUpdateCaptureDependencies(waiter, const_cast<hipGraphNode_t*>(d2), n2, hipStreamAddCaptureDependencies);
 }
+// 0 = not capturing, 1 = capturing, 2 = its capture has been invalidated (any further call on it fails), < 0 = -hipError_t
+extern "C" int madiff_stream_capture_status(hipStream_t stream) {
+  hipStreamCaptureStatus s = hipStreamCaptureStatusNone;
+  hipError_t rc = hipStreamIsCapturing(stream, &s);
+  if (rc != hipSuccess) { (void)hipGetLastError(); return -(int)rc; }
+  return s == hipStreamCaptureStatusActive ? 1 : (s == hipStreamCaptureStatusNone ? 0 : 2);
+}
 extern "C" int madiff_stream_wait_event(hipStream_t stream, void* event) {
   if (!event) return -1;
   return (int)hipStreamWaitEvent(stream, (hipEvent_t)event, 0);

@@ -29,6 +29,7 @@ _SIGS = {
     "madiff_event_record_external": [_vp, _vp],
     "madiff_stream_wait_event": [_vp, _vp],
     "madiff_capture_join": [_vp, _vp],
+    "madiff_stream_capture_status": [_vp],
     "madiff_conv_gn_mish_fwd": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i,
                                 _f, _i, _vp, _i, _vp, _i, _i, _vp],
     "madiff_conv_gn_mish_fwd_rv": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i,

@@ -110,14 +110,19 @@ def wait_stream(waiter, waited) -> None:
     capture, and when `waiter` is about to JOIN the capture, it is the ordinary event record + wait."""
     if waiter.cuda_stream == waited.cuda_stream:
         return
-    rc = lib.call_rc("madiff_capture_join", waiter.cuda_stream, waited.cuda_stream)
+    rc = lib.call_rc("madiff_capture_join", waiter.cuda_stream, waited.cuda_stream)     # (raises on a HIP error)
     if rc == 0:
         return
-    if rc != 1:                        # 1 = the two are not in one capture (the event path below); anything else is a HIP error
-        raise RuntimeError(f"madiff_capture_join failed with HIP error {rc}")
-    if stream_is_capturing(waiter) and not stream_is_capturing(waited):
-        # an event recorded outside a capture must not be waited on from inside it: this runtime aborts the process
+    # 1 = the two are not (both, actively) in one capture: the event path -- unless that would reach the runtime with
+    # something it answers by aborting the process
+    s1 = lib._lib.madiff_stream_capture_status(waiter.cuda_stream)
+    s2 = lib._lib.madiff_stream_capture_status(waited.cuda_stream)
+    if s1 == 2 or s2 == 2 or s1 < 0 or s2 < 0:
+        raise RuntimeError(f"wait_stream: the stream capture has been invalidated (status {s1}, {s2}); the step cannot be captured")
+    if s1 == 1 and s2 == 0:
         raise RuntimeError("wait_stream: a capturing stream was asked to wait for a stream outside its capture")
+    if s1 == 1 and s2 == 1:
+        raise RuntimeError("wait_stream: the two streams belong to different captures")
     waiter.wait_stream(waited)
 
 
