@@ -88,9 +88,9 @@ def test_folded_loss_and_gradient_match_accumulation(prec, name, discrete, share
             # bf16: the folded pass has twice the rows, so the tuner may serve a layer with another kernel variant and the
             # activations differ by bf16 roundings; the max-norm of a small gradient (attention q/k weights) then moves by
             # 4-10 % from run to run.  Bound the relative L2 error tightly and the max-norm only grossly.
-            l2 = float((p.grad - ref[k]).double().norm()) / max(float(ref[k].double().norm()), 1e-30)
             assert err < 0.25, (k, err)
-            err = l2
+            if ref[k].numel() > 1:      # (the scalar gammas keep the max-norm against the largest of them, as above)
+                err = float((p.grad - ref[k]).double().norm()) / max(float(ref[k].double().norm()), 1e-30)
         if err > worst:
             worst, worst_k = err, k
     # (bf16: GroupNorm statistics are per sample, so folding only reorders fp32 sums inside the weight-gradient GEMMs)
