@@ -78,6 +78,23 @@ def _ensure_splitk_workspace() -> None:
     _SPLITK_WS[dev] = (ws, cnt)
 
 
+def reset_splitk_slots() -> None:
+    """Hand every slot of the reduction-split workspace of the current device back (the library never does: a slot belongs
+    to one stream or one captured branch for good, and when the 16 are used up later captures run unsplit -- same
+    results to fp32 rounding of the partial sums, slower small-batch layers).  For a process that has dropped its captured
+    graphs, and for the test suite (every test starts with all slots, so that "graph == eager, bit for bit" does not
+    depend on how many captures ran before it).  Graphs captured earlier keep using their old slots: do not replay them
+    beside new work after this call."""
+    dev = torch.cuda.current_device()
+    if dev not in _SPLITK_WS:
+        return
+    torch.cuda.synchronize()
+    ws, cnt = _SPLITK_WS[dev]
+    cnt.zero_()
+    lib.call("madiff_set_splitk_workspace", ws.data_ptr(), ws.numel(), cnt.data_ptr(), cnt.numel())
+    torch.cuda.synchronize()
+
+
 def _stream() -> int:
     if torch.cuda.current_device() not in _SPLITK_WS:
         _ensure_splitk_workspace()

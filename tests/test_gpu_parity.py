@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import record_measured, rel_err
 from oracle import madiff_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +29,7 @@ def prec(request):
 def l2_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    return record_measured(float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)), "l2")
 
 
 def digest_check(params, names, digest, prec):
@@ -45,7 +45,7 @@ def digest_check(params, names, digest, prec):
             assert abs(l2 - row[2]) < floor, n
         else:
             worst = max(worst, abs(l2 - row[2]) / row[2])
-    return worst
+    return record_measured(worst, "gradnorm")
 
 
 def T(a, dev=None):
@@ -200,6 +200,7 @@ def sampled_gradient_check(params, names, samples, prec, prefix=""):
                 continue
         if e > worst:
             worst, worst_name = e, str(n)
+    record_measured(worst, "gradsmpl")
     return worst, worst_name
 
 
